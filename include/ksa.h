@@ -1,0 +1,139 @@
+/* libksa -- C ABI of the MI355X (gfx950) overlapped windowed-FFT spectrum / waterfall engine.
+ *
+ * Drop-in boundary for the numpy.fft hot path of hanishkvc/prgs-sdr-kspecanal.  The reference has
+ * no FFI of its own: its de-facto seam is the module-level callable `sdr_curscan(d)` of
+ * python/kspecanal.py (defined :351, called :464 / :523 / :636, rebound :531 / :543) plus the frame
+ * and scan accumulate blocks that consume its result (:464-484, :636-668, :696-697).  Every entry
+ * point below cites the reference lines it replaces ("K:" = python/kspecanal.py).
+ *
+ * Conventions: plain C types only; 0 = success, non-zero = error with text in ksa_last_error()
+ * (thread local).  "host" pointers are ordinary CPU memory, "dev" pointers are HIP device memory of
+ * the engine's device.  One engine = one GPU; no concurrent calls on one engine (the reference is
+ * single threaded: K:505, K:1118-1123).  All device work is enqueued on the engine's stream
+ * (ksa_set_stream) and host-pointer entry points synchronise that stream before returning.
+ */
+#ifndef KSA_H
+#define KSA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSA_ABI_VERSION 1
+#define KSA_HM_ROWS 128 /* waterfall history depth: maxHM K:448, fftHMMax K:611 */
+
+/* d['curScanCumuMode'] K:31-34, K:58, consumed by data_cumu K:124-147 */
+enum { KSA_CUMU_RAW = 0, KSA_CUMU_AVG = 1, KSA_CUMU_MAX = 2, KSA_CUMU_MIN = 3 };
+/* IQ sample formats: complex64 (what sdr.read_samples hands over, narrowed from K:335's complex128)
+ * and the dongle's native interleaved uint8 I,Q (pyrtlsdr packed_bytes_to_iq; K:301, K:339, K:346) */
+enum { KSA_FMT_C64 = 0, KSA_FMT_U8 = 1 };
+/* what the spectrum kernel writes per frame */
+enum {
+  KSA_OUT_LINEAR = 0,  /* sdr_curscan's return value: linear magnitude, fftshifted (K:391-396) */
+  KSA_OUT_DB = 1,      /* zeroSpan: LogNoGain, -inf kept (K:469, K:106-112) */
+  KSA_OUT_DB_CLIP = 2  /* scan: Clip2MinAmp then LogNoGain (K:640-641) */
+};
+
+typedef struct ksa_engine ksa_engine;
+
+typedef struct ksa_config {
+  int32_t abi_version;          /* KSA_ABI_VERSION */
+  int32_t device;               /* HIP device ordinal */
+  int32_t fft_size;             /* d['fftSize']: power of two, 16 .. 1048576 */
+  int32_t full_size;            /* d['fullSize'] K:926-929: samples per captured block */
+  int32_t num_windows;          /* windows actually transformed (K:385-390) */
+  const int32_t* window_starts; /* host[num_windows]: iStart = int(i*fftSize*nonOverlap) K:386 */
+  const float* window;          /* host[fft_size]: d['theWin'] K:932-936 */
+  double mag_scale;             /* 2*winAdj/fftSize with winAdj = N/sum(win): K:373, K:391 */
+  int32_t cumu_mode;            /* KSA_CUMU_*: within-block fold K:392-395 */
+  float gain;                   /* d['gain'] subtracted by LogNoGain K:109 */
+  float min_amp;                /* d['minAmp4Clip'] K:53, K:101 */
+  int32_t hm_width;             /* d['PltHeatMapWidth'] K:449-455 (zeroSpan) ; must divide fft_size */
+  int32_t max_frames;           /* largest batch handed to ksa_frames_dev / ksa_curscan_dev / steps per scan pass */
+  float u8_offset, u8_scale;    /* uint8 unpack (b - offset) / scale; 127.5 / 127.5 by default */
+  /* scan mode (0 = zeroSpan only): _scan_range K:568-698 */
+  int32_t scan_total_entries;   /* totalEntries = numGroups*fftSize K:599-600 */
+  int32_t scan_hop;             /* fftSize*scanRangeNonOverlap (validated integral, K:591-593) */
+  int32_t scan_hm_width;        /* d['xRes'] : width of the per-pass waterfall row K:614, K:697 */
+} ksa_config;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int ksa_abi_version(void);
+const char* ksa_last_error(void);
+/* Allocates tables, state and scratch on cfg->device.  Replaces the per-run setup of K:926-936. */
+int ksa_create(const ksa_config* cfg, ksa_engine** out);
+void ksa_destroy(ksa_engine* e);
+/* hip_stream: a hipStream_t (NULL = the device's default stream). */
+int ksa_set_stream(ksa_engine* e, void* hip_stream);
+int ksa_synchronize(ksa_engine* e);
+
+/* ---- sdr_curscan drop-ins (K:351-397) ------------------------------------------------------- */
+/* One captured block in, linear fftshifted magnitudes out (host memory both sides). */
+int ksa_curscan_c64(ksa_engine* e, const float* iq_host /* re,im interleaved [2*full_size] */,
+                    float* mag_host /* [fft_size] */);
+int ksa_curscan_u8(ksa_engine* e, const uint8_t* iq_host /* I,Q interleaved [2*full_size] */,
+                   float* mag_host /* [fft_size] */);
+/* Batched, device resident: nframes blocks spaced frame_stride samples apart -> out_dev[nframes][N]
+ * in out_mode units.  nframes <= max_frames.  No state is touched. */
+int ksa_curscan_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride,
+                    int32_t nframes, int32_t out_mode, float* out_dev);
+
+/* ---- zeroSpan frame accumulate (K:464-484), fused with curscan ------------------------------- */
+/* Process `nframes` blocks in order: Cur/Max/Min/Avg + the 128-row waterfall ring.  The batch is
+ * frames [first_index, first_index+nframes) of a logical run of total_frames frames (single GPU:
+ * first_index 0, total_frames = nframes); AVG uses the closed form of the reference's (a+x)/2
+ * recursion so that shards on several GPUs can be summed (ksa_partial_dev / ksa_commit).
+ * cur_db_dev (optional, [nframes][N]) receives every frame's dB spectrum; hm_rows_dev (optional,
+ * [nframes][hm_width]) every frame's waterfall row.  With commit != 0 the state is updated at once. */
+int ksa_frames_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride,
+                   int32_t nframes, int64_t first_index, int64_t total_frames,
+                   float* cur_db_dev, float* hm_rows_dev, int32_t commit);
+/* One block from host memory: the body of the reference's frame loop. */
+int ksa_frame_c64(ksa_engine* e, const float* iq_host);
+int ksa_frame_u8(ksa_engine* e, const uint8_t* iq_host);
+/* zeroSpanPlay (K:547-564 feeding K:469-484): accumulate an already computed linear spectrum. */
+int ksa_frame_spectrum(ksa_engine* e, const float* mag_host /* [fft_size], fftshifted */);
+/* Partial block of the last ksa_frames_dev(commit=0): float[4][N] = {max, cur-or--inf, min, sum}
+ * on the device -- all-reduce rows 0-1 with MAX, row 2 with MIN, row 3 with SUM across the ranks
+ * that share a run, then ksa_commit on every rank. */
+int ksa_partial_dev(ksa_engine* e, float** partial_dev);
+int ksa_commit(ksa_engine* e, int64_t total_frames);
+/* GUI toggles bDataMax/bDataMin/bDataAvg (K:71-73, K:471-476) */
+int ksa_set_flags(ksa_engine* e, int32_t b_max, int32_t b_min, int32_t b_avg);
+/* d['Fft.Adj'] subtracted before the waterfall row (K:400-411, K:478-480); NULL clears. */
+int ksa_set_adj(ksa_engine* e, const float* adj_host, int32_t n);
+int ksa_reset_state(ksa_engine* e);
+/* Any pointer may be NULL.  cur..avg: [fft_size]; hm: [KSA_HM_ROWS][hm_width]. */
+int ksa_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg, float* hm,
+                   int32_t* hm_index, int64_t* frames_seen);
+/* Device addresses of the persistent state (float[4][N]: cur,max,min,avg) and the ring. */
+int ksa_state_dev(ksa_engine* e, float** state_dev, float** hm_ring_dev);
+int ksa_set_hm_index(ksa_engine* e, int32_t hm_index);
+
+/* ---- scan stitch + accumulate (K:621-668, K:696-697) ----------------------------------------- */
+/* One full pass: nsteps tuned bands, block s at iq_dev + s*frame_stride.  step_ok (host, optional):
+ * 0 marks a band whose tune failed -> dummy ones (K:637-639). */
+int ksa_scan_pass_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride,
+                      int32_t nsteps, const uint8_t* step_ok);
+/* Same, from per-step dB spectra already on the device ([nsteps][N], KSA_OUT_DB_CLIP units). */
+int ksa_scan_stitch_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps);
+int ksa_scan_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg, float* hm,
+                        int32_t* hm_index, int64_t* passes);
+int ksa_scan_state_dev(ksa_engine* e, float** state_dev, float** hm_ring_dev);
+int ksa_scan_reset(ksa_engine* e);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* HIP-event timing of the spectrum kernel on the engine's stream: enable, run, then read the sum
+ * of kernel durations and the launch count since the last enable. */
+int ksa_prof_enable(ksa_engine* e, int32_t on);
+int ksa_prof_read(ksa_engine* e, double* spectrum_ms, int64_t* launches);
+/* Resources of the spectrum kernel chosen for this engine (for DESIGN.md / bench.py). */
+int ksa_kernel_info(ksa_engine* e, int32_t* threads, int32_t* lds_bytes, int32_t* vgprs,
+                    int32_t* grid, int32_t* path /* 0 = single-workgroup LDS FFT, 1 = four-step */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSA_H */

@@ -1,0 +1,640 @@
+// libksa: C ABI (include/ksa.h) over the gfx950 kernels in ksa_kernels.hpp.
+// Host-side orchestration only: table generation, scratch, launches, state hand-off.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ksa.h"
+#include "ksa_fourstep.hpp"
+#include "ksa_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+
+#define HIP_OK(call)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (call);                                                               \
+    if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+}  // namespace
+
+struct ksa_engine {
+  ksa_config cfg{};
+  hipStream_t stream = nullptr;
+  int num_cu = 0;
+  // tables
+  int* d_starts = nullptr;
+  int* d_start_last = nullptr;  // RAW mode: the last window only
+  float* d_window = nullptr;
+  float2* d_tw_mid = nullptr;
+  float2* d_tw_last = nullptr;
+  float* d_adj = nullptr;       // zeroSpan Fft.Adj or null
+  float* d_scan_adj = nullptr;
+  // scratch
+  void* d_iq_stage = nullptr;   // one block for the host-pointer entry points
+  float* d_frames = nullptr;    // [max_frames][N] per-frame spectra when the caller passes none
+  float* d_part = nullptr;      // [chunks][3][N]
+  float* d_partial = nullptr;   // [4][N]
+  float* d_state = nullptr;     // [4][N] cur,max,min,avg
+  float* d_hm = nullptr;        // [128][hm_width]
+  float* d_scan_state = nullptr;  // [4][total]
+  float* d_scan_hm = nullptr;     // [128][scan_hm_width]
+  ksa::FourStep four;           // N > 16384
+  // bookkeeping
+  long long frames_seen = 0;
+  int hm_index = 0;
+  int pending_frames = 0;       // frames of the last uncommitted batch
+  int b_max = 1, b_min = 1, b_avg = 1;
+  long long scan_passes = 0;
+  int scan_hm_index = 0;
+  int max_chunks = 1;
+  // launch config of the spectrum kernel
+  int path = 0, threads = 0, lds_bytes = 0, vgprs = 0, blocks_per_cu = 1;
+  // profiling
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  double prof_ms = 0;
+  long long prof_launches = 0;
+};
+
+namespace {
+
+using ksa::SpecParams;
+
+template <int N, int FMT>
+int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
+  using P = ksa::Plan<N>;
+  auto kfn = ksa::spectrum_kernel<N, FMT>;
+  if (configure_only) {
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES));
+    hipFuncAttributes attr;
+    HIP_OK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kfn)));
+    int occ = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, P::T, P::LDS_BYTES));
+    if (FMT == ksa::FMT_C64) {
+      e->threads = P::T;
+      e->lds_bytes = P::LDS_BYTES;
+      e->vgprs = attr.numRegs;
+      e->blocks_per_cu = std::max(1, occ);
+    }
+    return 0;
+  }
+  const int grid = std::max(1, std::min(p.nframes, e->num_cu * e->blocks_per_cu));
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), P::LDS_BYTES, e->stream, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template <int FMT>
+int launch_spec_n(ksa_engine* e, const SpecParams& p, bool cfg_only) {
+  switch (e->cfg.fft_size) {
+    case 16: return launch_spec_t<16, FMT>(e, p, cfg_only);
+    case 32: return launch_spec_t<32, FMT>(e, p, cfg_only);
+    case 64: return launch_spec_t<64, FMT>(e, p, cfg_only);
+    case 128: return launch_spec_t<128, FMT>(e, p, cfg_only);
+    case 256: return launch_spec_t<256, FMT>(e, p, cfg_only);
+    case 512: return launch_spec_t<512, FMT>(e, p, cfg_only);
+    case 1024: return launch_spec_t<1024, FMT>(e, p, cfg_only);
+    case 2048: return launch_spec_t<2048, FMT>(e, p, cfg_only);
+    case 4096: return launch_spec_t<4096, FMT>(e, p, cfg_only);
+    case 8192: return launch_spec_t<8192, FMT>(e, p, cfg_only);
+    case 16384: return launch_spec_t<16384, FMT>(e, p, cfg_only);
+    default: return fail("fft_size %d has no single-workgroup plan", e->cfg.fft_size);
+  }
+}
+
+int prof_begin(ksa_engine* e, hipEvent_t* a, hipEvent_t* b) {
+  *a = *b = nullptr;
+  if (!e->prof || e->prof_events.size() >= 8192) return 0;
+  HIP_OK(hipEventCreate(a));
+  HIP_OK(hipEventCreate(b));
+  HIP_OK(hipEventRecord(*a, e->stream));
+  return 0;
+}
+int prof_end(ksa_engine* e, hipEvent_t a, hipEvent_t b) {
+  if (!a) return 0;
+  HIP_OK(hipEventRecord(b, e->stream));
+  e->prof_events.emplace_back(a, b);
+  return 0;
+}
+
+// Spectrum stage for a batch: either the single-workgroup LDS FFT or the four-step path.
+int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int nframes, int out_mode,
+                 float* out, bool with_hm, float* hm_rows) {
+  const ksa_config& c = e->cfg;
+  if (fmt != KSA_FMT_C64 && fmt != KSA_FMT_U8) return fail("unknown sample format %d", fmt);
+  if (nframes < 1 || nframes > c.max_frames) return fail("nframes %d outside 1..max_frames(%d)", nframes, c.max_frames);
+  if (stride < 0) return fail("negative frame_stride");
+  SpecParams p{};
+  p.iq = iq;
+  p.frame_stride = stride;
+  p.frame_len = c.full_size;
+  p.nframes = nframes;
+  const bool raw = c.cumu_mode == KSA_CUMU_RAW;
+  p.nwin = raw ? 1 : c.num_windows;            // RAW keeps the last window only (K:135-136)
+  p.starts = raw ? e->d_start_last : e->d_starts;
+  p.window = e->d_window;
+  p.tw_mid = e->d_tw_mid;
+  p.tw_last = e->d_tw_last;
+  p.scale = (float)c.mag_scale;
+  p.cumu = (raw || c.cumu_mode == KSA_CUMU_AVG) ? ksa::CUMU_AVG : c.cumu_mode == KSA_CUMU_MAX ? ksa::CUMU_MAX : ksa::CUMU_MIN;
+  p.out_mode = out_mode;
+  p.gain = c.gain;
+  p.min_amp = c.min_amp;
+  p.u8_offset = c.u8_offset;
+  p.u8_inv_scale = 1.0f / c.u8_scale;
+  p.out = out;
+  p.hm_w = with_hm ? c.hm_width : 0;
+  p.adj = with_hm ? e->d_adj : nullptr;
+  p.hm_rows = with_hm ? hm_rows : nullptr;
+  p.hm_ring = with_hm ? e->d_hm : nullptr;
+  p.hm_index0 = e->hm_index;
+  p.hm_first = std::max(0, nframes - KSA_HM_ROWS);
+  hipEvent_t ea, eb;
+  if (prof_begin(e, &ea, &eb)) return 1;
+  int rc;
+  if (e->path == 1) {
+    rc = ksa::fourstep_run(e->four, p, fmt, e->stream, e->num_cu);
+    if (rc) return fail("four-step launch failed: %s", hipGetErrorString(hipGetLastError()));
+  } else {
+    rc = fmt == KSA_FMT_C64 ? launch_spec_n<ksa::FMT_C64>(e, p, false) : launch_spec_n<ksa::FMT_U8>(e, p, false);
+    if (rc) return rc;
+  }
+  return prof_end(e, ea, eb);
+}
+
+int run_accumulate(ksa_engine* e, const float* db, int nframes, long long first_index, long long total) {
+  const int n = e->cfg.fft_size;
+  ksa::AccParams a{};
+  a.db = db;
+  a.n = n;
+  a.nframes = nframes;
+  a.first_index = first_index;
+  a.total_frames = total;
+  a.has_prev = e->frames_seen > 0;
+  int chunks = std::min(e->max_chunks, std::max(1, nframes / 32));
+  a.chunk = (nframes + chunks - 1) / chunks;
+  chunks = (nframes + a.chunk - 1) / a.chunk;
+  a.part = e->d_part;
+  const int tb = 256, gx = (n + tb - 1) / tb;
+  hipLaunchKernelGGL(ksa::accumulate_partial_kernel, dim3(gx, chunks), dim3(tb), 0, e->stream, a);
+  const int owns_last = first_index + nframes == total;
+  hipLaunchKernelGGL(ksa::accumulate_reduce_kernel, dim3(gx), dim3(tb), 0, e->stream, e->d_part, chunks, n,
+                     db + (long long)(nframes - 1) * n, owns_last, e->d_partial);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int do_commit(ksa_engine* e, long long total, int local_frames) {
+  const int n = e->cfg.fft_size;
+  const int tb = 256, gx = (n + tb - 1) / tb;
+  hipLaunchKernelGGL(ksa::commit_kernel, dim3(gx), dim3(tb), 0, e->stream, e->d_partial, e->d_state, n,
+                     e->frames_seen > 0 ? 1 : 0, total, e->b_max, e->b_min, e->b_avg);
+  HIP_OK(hipGetLastError());
+  e->frames_seen += total;
+  e->hm_index = (int)((e->hm_index + local_frames) % KSA_HM_ROWS);
+  e->pending_frames = 0;
+  return 0;
+}
+
+template <typename T>
+int upload(T** dst, const T* src, size_t count) {
+  HIP_OK(hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(count, 1) * sizeof(T)));
+  if (count) HIP_OK(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int fill(ksa_engine* e, float* dst, long long n, float v) {
+  if (n <= 0) return 0;
+  const int tb = 256;
+  const int gx = (int)std::min<long long>((n + tb - 1) / tb, 4096);
+  hipLaunchKernelGGL(ksa::fill_kernel, dim3(gx), dim3(tb), 0, e->stream, dst, n, v);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int scan_reset(ksa_engine* e) {
+  const ksa_config& c = e->cfg;
+  if (!c.scan_total_entries) return fail("engine was created without scan geometry");
+  // K:603-608: Cur = Max = Avg = dB(minAmp4Clip), Min = dB(1.0); K:613-614 ring = minAmp4Clip (linear)
+  const float floor_db = (float)(10.0 * std::log10((double)c.min_amp) - (double)c.gain);
+  const float one_db = (float)(10.0 * std::log10(1.0) - (double)c.gain);
+  const long long t = c.scan_total_entries;
+  if (fill(e, e->d_scan_state, t, floor_db)) return 1;
+  if (fill(e, e->d_scan_state + t, t, floor_db)) return 1;
+  if (fill(e, e->d_scan_state + 2 * t, t, one_db)) return 1;
+  if (fill(e, e->d_scan_state + 3 * t, t, floor_db)) return 1;
+  if (fill(e, e->d_scan_hm, (long long)KSA_HM_ROWS * c.scan_hm_width, c.min_amp)) return 1;
+  e->scan_passes = 0;
+  e->scan_hm_index = 0;
+  return 0;
+}
+
+size_t sample_bytes(int fmt) { return fmt == KSA_FMT_C64 ? 8 : 2; }
+
+}  // namespace
+
+extern "C" {
+
+int ksa_abi_version(void) { return KSA_ABI_VERSION; }
+const char* ksa_last_error(void) { return g_err.c_str(); }
+
+int ksa_create(const ksa_config* cfg, ksa_engine** out) {
+  if (!cfg || !out) return fail("null argument");
+  *out = nullptr;
+  if (cfg->abi_version != KSA_ABI_VERSION) return fail("ABI version %d, library is %d", cfg->abi_version, KSA_ABI_VERSION);
+  const int n = cfg->fft_size;
+  if (!is_pow2(n) || n < 16 || n > (1 << 20)) return fail("fft_size %d must be a power of two in 16..1048576", n);
+  if (cfg->full_size < n) return fail("full_size %d < fft_size %d", cfg->full_size, n);
+  if (cfg->num_windows < 1 || !cfg->window_starts || !cfg->window) return fail("window table / starts missing");
+  for (int i = 0; i < cfg->num_windows; ++i)
+    if (cfg->window_starts[i] < 0 || cfg->window_starts[i] + n > cfg->full_size)
+      return fail("window %d start %d runs past the block", i, cfg->window_starts[i]);
+  if (cfg->cumu_mode < KSA_CUMU_RAW || cfg->cumu_mode > KSA_CUMU_MIN) return fail("unknown cumu_mode %d", cfg->cumu_mode);
+  if (cfg->hm_width < 0 || (cfg->hm_width && (n % cfg->hm_width || !is_pow2(cfg->hm_width))))
+    return fail("hm_width %d must be a power of two dividing fft_size", cfg->hm_width);
+  if (cfg->max_frames < 1) return fail("max_frames must be >= 1");
+  if (!(cfg->u8_scale != 0.f)) return fail("u8_scale must be non-zero");
+  if (cfg->scan_total_entries) {
+    if (cfg->scan_hop < 1 || cfg->scan_hop > n) return fail("scan_hop %d outside 1..fft_size", cfg->scan_hop);
+    if (cfg->scan_hm_width < 1 || cfg->scan_total_entries % cfg->scan_hm_width)
+      return fail("scan_hm_width %d must divide scan_total_entries %d", cfg->scan_hm_width, cfg->scan_total_entries);
+  }
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail("device %d not present (%d visible)", cfg->device, ndev);
+  HIP_OK(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, cfg->device));
+
+  ksa_engine* e = new ksa_engine();
+  e->cfg = *cfg;
+  e->cfg.window_starts = nullptr;
+  e->cfg.window = nullptr;
+  e->num_cu = prop.multiProcessorCount;
+  int rc = 0;
+  auto bail = [&](int r) { ksa_destroy(e); return r; };
+
+  if ((rc = upload(&e->d_starts, cfg->window_starts, (size_t)cfg->num_windows))) return bail(rc);
+  if ((rc = upload(&e->d_start_last, cfg->window_starts + cfg->num_windows - 1, 1))) return bail(rc);
+  if ((rc = upload(&e->d_window, cfg->window, (size_t)n))) return bail(rc);
+
+  if (n <= 16384) {
+    e->path = 0;
+    // twiddles in double, stored as float: middle passes [15][p] each, last pass [15][N/16]
+    const int log2n = ksa::ilog2(n);
+    const int m = (log2n + 3) / 4;
+    const int r0 = 1 << (log2n - 4 * (m - 1));
+    std::vector<float2> mid, last;
+    int pcur = r0;
+    for (int s = 1; s < m; ++s) {
+      std::vector<float2>& dst = s < m - 1 ? mid : last;
+      for (int t = 1; t < 16; ++t)
+        for (int k = 0; k < pcur; ++k) {
+          const double ang = -2.0 * M_PI * (double)t * (double)k / ((double)pcur * 16.0);
+          dst.push_back(make_float2((float)std::cos(ang), (float)std::sin(ang)));
+        }
+      pcur *= 16;
+    }
+    if ((rc = upload(&e->d_tw_mid, mid.data(), mid.size()))) return bail(rc);
+    if ((rc = upload(&e->d_tw_last, last.data(), last.size()))) return bail(rc);
+    SpecParams dummy{};
+    if ((rc = launch_spec_n<ksa::FMT_C64>(e, dummy, true))) return bail(rc);
+    if ((rc = launch_spec_n<ksa::FMT_U8>(e, dummy, true))) return bail(rc);
+  } else {
+    e->path = 1;
+    if (ksa::fourstep_create(e->four, n, cfg->num_windows, cfg->max_frames, e->num_cu)) return bail(fail("four-step setup failed for fft_size %d: %s", n, hipGetErrorString(hipGetLastError())));
+    e->threads = e->four.threads;
+    e->lds_bytes = e->four.lds_bytes;
+    e->vgprs = e->four.vgprs;
+    e->blocks_per_cu = 1;
+  }
+
+  const size_t nn = (size_t)n;
+  e->max_chunks = (int)std::max<size_t>(1, std::min<size_t>(256, (64u << 20) / (3 * nn * 4)));
+  hipError_t he;
+#define ALLOC(ptr, bytes)                                                        \
+  if ((he = hipMalloc(reinterpret_cast<void**>(&(ptr)), (bytes))) != hipSuccess) \
+    return bail(fail("hipMalloc(%zu) for %s: %s", (size_t)(bytes), #ptr, hipGetErrorString(he)));
+  ALLOC(e->d_iq_stage, (size_t)cfg->full_size * 8);
+  ALLOC(e->d_frames, (size_t)cfg->max_frames * nn * 4);
+  ALLOC(e->d_part, (size_t)e->max_chunks * 3 * nn * 4);
+  ALLOC(e->d_partial, 4 * nn * 4);
+  ALLOC(e->d_state, 4 * nn * 4);
+  if (cfg->hm_width) ALLOC(e->d_hm, (size_t)KSA_HM_ROWS * cfg->hm_width * 4);
+  if (cfg->scan_total_entries) {
+    ALLOC(e->d_scan_state, (size_t)4 * cfg->scan_total_entries * 4);
+    ALLOC(e->d_scan_hm, (size_t)KSA_HM_ROWS * cfg->scan_hm_width * 4);
+  }
+#undef ALLOC
+  if (ksa_reset_state(e)) return bail(1);
+  if (cfg->scan_total_entries && scan_reset(e)) return bail(1);
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(fail("initial sync failed"));
+  *out = e;
+  return 0;
+}
+
+void ksa_destroy(ksa_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->cfg.device);
+  hipDeviceSynchronize();
+  for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  void* ptrs[] = {e->d_starts, e->d_start_last, e->d_window, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
+                  e->d_iq_stage, e->d_frames, e->d_part, e->d_partial, e->d_state, e->d_hm, e->d_scan_state, e->d_scan_hm};
+  for (void* p : ptrs) if (p) hipFree(p);
+  ksa::fourstep_destroy(e->four);
+  delete e;
+}
+
+int ksa_set_stream(ksa_engine* e, void* hip_stream) {
+  if (!e) return fail("null engine");
+  e->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return 0;
+}
+
+int ksa_synchronize(ksa_engine* e) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int ksa_curscan_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride, int32_t nframes,
+                    int32_t out_mode, float* out_dev) {
+  if (!e || !iq_dev || !out_dev) return fail("null argument");
+  if (out_mode < KSA_OUT_LINEAR || out_mode > KSA_OUT_DB_CLIP) return fail("unknown out_mode %d", out_mode);
+  HIP_OK(hipSetDevice(e->cfg.device));
+  return run_spectrum(e, iq_dev, fmt, frame_stride, nframes, out_mode, out_dev, false, nullptr);
+}
+
+static int curscan_host(ksa_engine* e, const void* iq_host, int fmt, float* mag_host) {
+  if (!e || !iq_host || !mag_host) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  HIP_OK(hipMemcpyAsync(e->d_iq_stage, iq_host, (size_t)e->cfg.full_size * sample_bytes(fmt), hipMemcpyHostToDevice, e->stream));
+  if (run_spectrum(e, e->d_iq_stage, fmt, 0, 1, KSA_OUT_LINEAR, e->d_frames, false, nullptr)) return 1;
+  HIP_OK(hipMemcpyAsync(mag_host, e->d_frames, (size_t)e->cfg.fft_size * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int ksa_curscan_c64(ksa_engine* e, const float* iq_host, float* mag_host) { return curscan_host(e, iq_host, KSA_FMT_C64, mag_host); }
+int ksa_curscan_u8(ksa_engine* e, const uint8_t* iq_host, float* mag_host) { return curscan_host(e, iq_host, KSA_FMT_U8, mag_host); }
+
+int ksa_frames_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride, int32_t nframes,
+                   int64_t first_index, int64_t total_frames, float* cur_db_dev, float* hm_rows_dev, int32_t commit) {
+  if (!e || !iq_dev) return fail("null argument");
+  if (first_index < 0 || first_index + nframes > total_frames) return fail("batch [%lld,+%d) outside run of %lld frames", (long long)first_index, nframes, (long long)total_frames);
+  HIP_OK(hipSetDevice(e->cfg.device));
+  float* db = cur_db_dev ? cur_db_dev : e->d_frames;
+  if (run_spectrum(e, iq_dev, fmt, frame_stride, nframes, KSA_OUT_DB, db, e->cfg.hm_width > 0, hm_rows_dev)) return 1;
+  if (run_accumulate(e, db, nframes, first_index, total_frames)) return 1;
+  e->pending_frames = nframes;
+  if (commit) return do_commit(e, total_frames, nframes);
+  return 0;
+}
+
+static int frame_host(ksa_engine* e, const void* iq_host, int fmt) {
+  if (!e || !iq_host) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  HIP_OK(hipMemcpyAsync(e->d_iq_stage, iq_host, (size_t)e->cfg.full_size * sample_bytes(fmt), hipMemcpyHostToDevice, e->stream));
+  if (ksa_frames_dev(e, e->d_iq_stage, fmt, 0, 1, 0, 1, nullptr, nullptr, 1)) return 1;
+  HIP_OK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int ksa_frame_c64(ksa_engine* e, const float* iq_host) { return frame_host(e, iq_host, KSA_FMT_C64); }
+int ksa_frame_u8(ksa_engine* e, const uint8_t* iq_host) { return frame_host(e, iq_host, KSA_FMT_U8); }
+
+int ksa_frame_spectrum(ksa_engine* e, const float* mag_host) {
+  if (!e || !mag_host) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  const int n = e->cfg.fft_size;
+  float* lin = reinterpret_cast<float*>(e->d_iq_stage);  // full_size*8 bytes >= N*4
+  HIP_OK(hipMemcpyAsync(lin, mag_host, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  ksa::DbRowParams p{};
+  p.lin = lin;
+  p.out = e->d_frames;
+  p.n = n;
+  p.nframes = 1;
+  p.gain = e->cfg.gain;
+  p.hm_w = e->cfg.hm_width;
+  p.adj = e->d_adj;
+  p.hm_rows = nullptr;
+  p.hm_ring = e->d_hm;
+  p.hm_index0 = e->hm_index;
+  p.hm_first = 0;
+  hipLaunchKernelGGL(ksa::db_rows_kernel, dim3(std::max(1, std::min(64, n / 256)), 1), dim3(256), 0, e->stream, p);
+  HIP_OK(hipGetLastError());
+  if (run_accumulate(e, e->d_frames, 1, 0, 1)) return 1;
+  if (do_commit(e, 1, 1)) return 1;
+  HIP_OK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int ksa_partial_dev(ksa_engine* e, float** partial_dev) {
+  if (!e || !partial_dev) return fail("null argument");
+  *partial_dev = e->d_partial;
+  return 0;
+}
+
+int ksa_commit(ksa_engine* e, int64_t total_frames) {
+  if (!e) return fail("null engine");
+  if (e->pending_frames <= 0) return fail("ksa_commit without a pending ksa_frames_dev(commit=0)");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  return do_commit(e, total_frames, e->pending_frames);
+}
+
+int ksa_set_flags(ksa_engine* e, int32_t b_max, int32_t b_min, int32_t b_avg) {
+  if (!e) return fail("null engine");
+  e->b_max = b_max != 0;
+  e->b_min = b_min != 0;
+  e->b_avg = b_avg != 0;
+  return 0;
+}
+
+int ksa_set_adj(ksa_engine* e, const float* adj_host, int32_t n) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  if (!adj_host) {
+    if (e->d_adj) hipFree(e->d_adj);
+    if (e->d_scan_adj) hipFree(e->d_scan_adj);
+    e->d_adj = e->d_scan_adj = nullptr;
+    return 0;
+  }
+  float** slot = nullptr;
+  if (n == e->cfg.fft_size) slot = &e->d_adj;
+  else if (e->cfg.scan_total_entries && n == e->cfg.scan_total_entries) slot = &e->d_scan_adj;
+  else return fail("adj length %d matches neither fft_size nor scan_total_entries", n);
+  if (*slot) hipFree(*slot);
+  *slot = nullptr;
+  return upload(slot, adj_host, (size_t)n);
+}
+
+int ksa_reset_state(ksa_engine* e) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  HIP_OK(hipMemsetAsync(e->d_state, 0, (size_t)4 * e->cfg.fft_size * 4, e->stream));
+  if (e->d_hm) HIP_OK(hipMemsetAsync(e->d_hm, 0, (size_t)KSA_HM_ROWS * e->cfg.hm_width * 4, e->stream));  // np.zeros K:456
+  e->frames_seen = 0;
+  e->hm_index = 0;
+  e->pending_frames = 0;
+  return 0;
+}
+
+int ksa_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg, float* hm, int32_t* hm_index,
+                   int64_t* frames_seen) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  const size_t nb = (size_t)e->cfg.fft_size * 4;
+  float* dst[4] = {cur, max, min, avg};
+  for (int i = 0; i < 4; ++i)
+    if (dst[i]) HIP_OK(hipMemcpyAsync(dst[i], e->d_state + (size_t)i * e->cfg.fft_size, nb, hipMemcpyDeviceToHost, e->stream));
+  if (hm) {
+    if (!e->d_hm) return fail("engine has no waterfall (hm_width 0)");
+    HIP_OK(hipMemcpyAsync(hm, e->d_hm, (size_t)KSA_HM_ROWS * e->cfg.hm_width * 4, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIP_OK(hipStreamSynchronize(e->stream));
+  if (hm_index) *hm_index = e->hm_index;
+  if (frames_seen) *frames_seen = e->frames_seen;
+  return 0;
+}
+
+int ksa_state_dev(ksa_engine* e, float** state_dev, float** hm_ring_dev) {
+  if (!e) return fail("null engine");
+  if (state_dev) *state_dev = e->d_state;
+  if (hm_ring_dev) *hm_ring_dev = e->d_hm;
+  return 0;
+}
+
+int ksa_set_hm_index(ksa_engine* e, int32_t hm_index) {
+  if (!e) return fail("null engine");
+  if (hm_index < 0 || hm_index >= KSA_HM_ROWS) return fail("hm_index %d outside the ring", hm_index);
+  e->hm_index = hm_index;
+  return 0;
+}
+
+int ksa_scan_stitch_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps) {
+  if (!e || !step_db_dev) return fail("null argument");
+  const ksa_config& c = e->cfg;
+  if (!c.scan_total_entries) return fail("engine was created without scan geometry");
+  if (nsteps < 1) return fail("nsteps must be >= 1");
+  HIP_OK(hipSetDevice(c.device));
+  ksa::StitchParams s{};
+  s.step_db = step_db_dev;
+  s.n = c.fft_size;
+  s.nsteps = nsteps;
+  s.hop = c.scan_hop;
+  s.total = c.scan_total_entries;
+  s.state = e->d_scan_state;
+  s.first_pass = e->scan_passes == 0;
+  s.b_max = e->b_max;
+  s.b_min = e->b_min;
+  const int tb = 256;
+  hipLaunchKernelGGL(ksa::scan_stitch_kernel, dim3((s.total + tb - 1) / tb), dim3(tb), 0, e->stream, s);
+  const int g = c.scan_total_entries / c.scan_hm_width;
+  hipLaunchKernelGGL(ksa::rowmax_kernel, dim3((c.scan_hm_width + tb - 1) / tb), dim3(tb), 0, e->stream,
+                     e->d_scan_state + (size_t)3 * s.total, e->d_scan_adj, c.scan_hm_width, g,
+                     e->d_scan_hm + (size_t)e->scan_hm_index * c.scan_hm_width);
+  HIP_OK(hipGetLastError());
+  e->scan_passes += 1;
+  e->scan_hm_index = (e->scan_hm_index + 1) % KSA_HM_ROWS;  // K:732
+  return 0;
+}
+
+int ksa_scan_pass_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride, int32_t nsteps,
+                      const uint8_t* step_ok) {
+  if (!e || !iq_dev) return fail("null argument");
+  if (!e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  if (run_spectrum(e, iq_dev, fmt, frame_stride, nsteps, KSA_OUT_DB_CLIP, e->d_frames, false, nullptr)) return 1;
+  if (step_ok) {
+    // dummy band: ones(fftSize) through Clip2MinAmp + LogNoGain (K:637-641)
+    const float v = (float)(10.0 * std::log10(std::max(1.0, (double)e->cfg.min_amp)) - (double)e->cfg.gain);
+    for (int s = 0; s < nsteps; ++s)
+      if (!step_ok[s] && fill(e, e->d_frames + (size_t)s * e->cfg.fft_size, e->cfg.fft_size, v)) return 1;
+  }
+  return ksa_scan_stitch_dev(e, e->d_frames, nsteps);
+}
+
+int ksa_scan_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg, float* hm, int32_t* hm_index,
+                        int64_t* passes) {
+  if (!e) return fail("null engine");
+  if (!e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  const size_t t = (size_t)e->cfg.scan_total_entries;
+  float* dst[4] = {cur, max, min, avg};
+  for (int i = 0; i < 4; ++i)
+    if (dst[i]) HIP_OK(hipMemcpyAsync(dst[i], e->d_scan_state + i * t, t * 4, hipMemcpyDeviceToHost, e->stream));
+  if (hm) HIP_OK(hipMemcpyAsync(hm, e->d_scan_hm, (size_t)KSA_HM_ROWS * e->cfg.scan_hm_width * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  if (hm_index) *hm_index = e->scan_hm_index;
+  if (passes) *passes = e->scan_passes;
+  return 0;
+}
+
+int ksa_scan_state_dev(ksa_engine* e, float** state_dev, float** hm_ring_dev) {
+  if (!e) return fail("null engine");
+  if (state_dev) *state_dev = e->d_scan_state;
+  if (hm_ring_dev) *hm_ring_dev = e->d_scan_hm;
+  return 0;
+}
+
+int ksa_scan_reset(ksa_engine* e) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipSetDevice(e->cfg.device));
+  return scan_reset(e);
+}
+
+int ksa_prof_enable(ksa_engine* e, int32_t on) {
+  if (!e) return fail("null engine");
+  for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  e->prof_events.clear();
+  e->prof = on != 0;
+  return 0;
+}
+
+int ksa_prof_read(ksa_engine* e, double* spectrum_ms, int64_t* launches) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipStreamSynchronize(e->stream));
+  double ms = 0;
+  for (auto& pr : e->prof_events) {
+    float t = 0;
+    HIP_OK(hipEventElapsedTime(&t, pr.first, pr.second));
+    ms += t;
+  }
+  if (spectrum_ms) *spectrum_ms = ms;
+  if (launches) *launches = (int64_t)e->prof_events.size();
+  return 0;
+}
+
+int ksa_kernel_info(ksa_engine* e, int32_t* threads, int32_t* lds_bytes, int32_t* vgprs, int32_t* grid, int32_t* path) {
+  if (!e) return fail("null engine");
+  if (threads) *threads = e->threads;
+  if (lds_bytes) *lds_bytes = e->lds_bytes;
+  if (vgprs) *vgprs = e->vgprs;
+  if (grid) *grid = e->num_cu * e->blocks_per_cu;
+  if (path) *path = e->path;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// Register-resident small DFTs and the per-size plan of the single-workgroup LDS FFT (gfx950).
+//
+// Replaces numpy.fft.fft at python/kspecanal.py:391 (forward DFT, e^{-2*pi*i*n*k/N}, unnormalised).
+//
+// Plan: N = R0 * 16^(M-1).  Every thread owns 16 complex points in VGPRs (L = N/16 threads per
+// transform).  Pass 0 is radix R0 (16/R0 butterflies per thread, no twiddles, inputs straight
+// from HBM/L2 with the window multiply fused); passes 1..M-1 are radix 16 with one butterfly per
+// thread.  Between passes the 16 results are exchanged through LDS (Stockham autosort, so the
+// last pass leaves natural-order bins l + L*t in the registers of thread l).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ksa {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// a * w
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
+  return make_float2(fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y));
+}
+
+constexpr float kSqrtHalf = 0.70710678118654752440f;
+constexpr float kCosPi8 = 0.92387953251128675613f;
+constexpr float kSinPi8 = 0.38268343236508977173f;
+
+// v *= W16^M (forward: e^{-2*pi*i*M/16}); only the exponents a 4x4 split needs.
+template <int M>
+__device__ __forceinline__ float2 mul_w16(float2 v) {
+  if constexpr (M == 0) return v;
+  else if constexpr (M == 1) return cmul(v, make_float2(kCosPi8, -kSinPi8));
+  else if constexpr (M == 2) return make_float2((v.x + v.y) * kSqrtHalf, (v.y - v.x) * kSqrtHalf);
+  else if constexpr (M == 3) return cmul(v, make_float2(kSinPi8, -kCosPi8));
+  else if constexpr (M == 4) return make_float2(v.y, -v.x);
+  else if constexpr (M == 6) return make_float2((v.y - v.x) * kSqrtHalf, -(v.x + v.y) * kSqrtHalf);
+  else if constexpr (M == 9) return cmul(v, make_float2(-kCosPi8, kSinPi8));
+  else { static_assert(M < 0, "unsupported W16 exponent"); return v; }
+}
+
+template <int BASE, int STRIDE>
+__device__ __forceinline__ void dft2(float2 (&v)[16]) {
+  float2 a = v[BASE], b = v[BASE + STRIDE];
+  v[BASE] = cadd(a, b);
+  v[BASE + STRIDE] = csub(a, b);
+}
+
+// natural-order in-place radix-4 on v[BASE + STRIDE*{0,1,2,3}]
+template <int BASE, int STRIDE>
+__device__ __forceinline__ void dft4(float2 (&v)[16]) {
+  float2 a0 = v[BASE], a1 = v[BASE + STRIDE], a2 = v[BASE + 2 * STRIDE], a3 = v[BASE + 3 * STRIDE];
+  float2 s0 = cadd(a0, a2), d0 = csub(a0, a2);
+  float2 s1 = cadd(a1, a3), d1 = csub(a1, a3);
+  v[BASE] = cadd(s0, s1);
+  v[BASE + 2 * STRIDE] = csub(s0, s1);
+  v[BASE + STRIDE] = make_float2(d0.x + d1.y, d0.y - d1.x);      // d0 - j*d1
+  v[BASE + 3 * STRIDE] = make_float2(d0.x - d1.y, d0.y + d1.x);  // d0 + j*d1
+}
+
+// radix-8 on v[BASE..BASE+7]; position BASE+P ends up holding X[perm8(P)]
+template <int BASE>
+__device__ __forceinline__ void dft8(float2 (&v)[16]) {
+  dft4<BASE + 0, 2>(v);
+  dft4<BASE + 1, 2>(v);
+  v[BASE + 3] = mul_w16<2>(v[BASE + 3]);  // W8^1
+  v[BASE + 5] = mul_w16<4>(v[BASE + 5]);  // W8^2
+  v[BASE + 7] = mul_w16<6>(v[BASE + 7]);  // W8^3
+  dft2<BASE + 0, 1>(v);
+  dft2<BASE + 2, 1>(v);
+  dft2<BASE + 4, 1>(v);
+  dft2<BASE + 6, 1>(v);
+}
+
+// radix-16 on v[0..15] as 4x4; position P ends up holding X[perm16(P)]
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+  dft4<0, 4>(v);
+  dft4<1, 4>(v);
+  dft4<2, 4>(v);
+  dft4<3, 4>(v);
+  // position 4*k1 + n2 holds y[n2][k1]; multiply by W16^(n2*k1)
+  v[5] = mul_w16<1>(v[5]);
+  v[6] = mul_w16<2>(v[6]);
+  v[7] = mul_w16<3>(v[7]);
+  v[9] = mul_w16<2>(v[9]);
+  v[10] = mul_w16<4>(v[10]);
+  v[11] = mul_w16<6>(v[11]);
+  v[13] = mul_w16<3>(v[13]);
+  v[14] = mul_w16<6>(v[14]);
+  v[15] = mul_w16<9>(v[15]);
+  dft4<0, 1>(v);
+  dft4<4, 1>(v);
+  dft4<8, 1>(v);
+  dft4<12, 1>(v);
+}
+
+// radix-16 of (w^t * v[t]) with the input twiddles folded into the 4x4 split: t = 4*n1 + n2, so
+// w^t = w^(4*n1) * w^n2 -- three twiddles before the first radix-4 level, three after it.  Needs
+// only w^1, w^2, w^3, w^4, w^8, w^12 (6 instead of 15 live twiddles) for 9 extra complex multiplies.
+__device__ __forceinline__ void dft16_tw(float2 (&v)[16], float2 w1, float2 w2, float2 w3, float2 w4,
+                                         float2 w8, float2 w12) {
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) {
+    v[4 + n2] = cmul(v[4 + n2], w4);
+    v[8 + n2] = cmul(v[8 + n2], w8);
+    v[12 + n2] = cmul(v[12 + n2], w12);
+  }
+  dft4<0, 4>(v);
+  dft4<1, 4>(v);
+  dft4<2, 4>(v);
+  dft4<3, 4>(v);
+  v[1] = cmul(v[1], w1);
+  v[2] = cmul(v[2], w2);
+  v[3] = cmul(v[3], w3);
+  v[5] = cmul(mul_w16<1>(v[5]), w1);
+  v[6] = cmul(mul_w16<2>(v[6]), w2);
+  v[7] = cmul(mul_w16<3>(v[7]), w3);
+  v[9] = cmul(mul_w16<2>(v[9]), w1);
+  v[10] = cmul(mul_w16<4>(v[10]), w2);
+  v[11] = cmul(mul_w16<6>(v[11]), w3);
+  v[13] = cmul(mul_w16<3>(v[13]), w1);
+  v[14] = cmul(mul_w16<6>(v[14]), w2);
+  v[15] = cmul(mul_w16<9>(v[15]), w3);
+  dft4<0, 1>(v);
+  dft4<4, 1>(v);
+  dft4<8, 1>(v);
+  dft4<12, 1>(v);
+}
+
+// output index held at register position P after the in-place transforms above
+template <int R>
+__host__ __device__ constexpr int perm(int p) {
+  return R == 16 ? ((p >> 2) | ((p & 3) << 2)) : R == 8 ? ((p >> 1) | ((p & 1) << 2)) : p;
+}
+
+// all B = 16/R0 first-pass butterflies of one thread; registers are v[b*R0 + t]
+template <int R0>
+__device__ __forceinline__ void dft_first(float2 (&v)[16]) {
+  if constexpr (R0 == 16) {
+    dft16(v);
+  } else if constexpr (R0 == 8) {
+    dft8<0>(v);
+    dft8<8>(v);
+  } else if constexpr (R0 == 4) {
+    dft4<0, 1>(v);
+    dft4<4, 1>(v);
+    dft4<8, 1>(v);
+    dft4<12, 1>(v);
+  } else {
+    dft2<0, 1>(v); dft2<2, 1>(v); dft2<4, 1>(v); dft2<6, 1>(v);
+    dft2<8, 1>(v); dft2<10, 1>(v); dft2<12, 1>(v); dft2<14, 1>(v);
+  }
+}
+
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+
+// Static plan for one transform size.
+template <int N>
+struct Plan {
+  static_assert(N >= 16 && (N & (N - 1)) == 0, "N must be a power of two >= 16");
+  static constexpr int LOG2N = ilog2(N);
+  static constexpr int M = (LOG2N + 3) / 4;                 // passes
+  static constexpr int R0 = 1 << (LOG2N - 4 * (M - 1));     // first-pass radix: 2, 4, 8 or 16
+  static constexpr int B0 = 16 / R0;                        // first-pass butterflies per thread
+  static constexpr int L = N / 16;                          // threads per transform
+  static constexpr int T = L < 64 ? 64 : L;                 // workgroup size
+  static constexpr int S = T / L;                           // transforms in flight per workgroup
+  static constexpr int NPAD = N + N / 16;                   // padded LDS complex elements per transform
+  // middle-pass twiddle tables (passes 1..M-2): 15*p entries each, p = R0*16^(s-1)
+  static constexpr int mid_entries() {
+    int tot = 0, p = R0;
+    for (int s = 1; s < M - 1; ++s) { tot += 15 * p; p *= 16; }
+    return tot;
+  }
+  static constexpr int MID = mid_entries();
+  static constexpr int P_LAST = N / 16;                     // p of the last pass (M >= 2)
+  static constexpr int LDS_BYTES = (S * NPAD + MID) * 8;
+};
+
+__host__ __device__ constexpr int padi(int i) { return i + (i >> 4); }
+
+}  // namespace ksa

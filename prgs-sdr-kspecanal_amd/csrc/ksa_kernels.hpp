@@ -1,0 +1,416 @@
+// HIP kernels of the spectrum / waterfall path for gfx950 (MI355X).
+//
+//  spectrum_kernel<N,FMT>   rows A0,A4-A9,A12 of SURVEY.md section 8: unpack, window, FFT, |X|,
+//                           fold over the block's windows, fftshift, dB, waterfall row.
+//                           One workgroup walks frames (persistent, grid-stride); the transform
+//                           lives in VGPRs + LDS, the block of IQ is read from HBM once.
+//  accumulate_*             row A10: Max/Min/Avg/Cur over a batch of frames (K:470-476)
+//  scan_stitch_kernel       row A13: band stitch + per-pass accumulate (K:622-668)
+//  rowmax_kernel            row A12 for the scan: per-pass waterfall row from Fft.Avg (K:696-697)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ksa_fft.hpp"
+
+namespace ksa {
+
+enum { CUMU_AVG = 1, CUMU_MAX = 2, CUMU_MIN = 3 };
+enum { OUT_LINEAR = 0, OUT_DB = 1, OUT_DB_CLIP = 2 };
+enum { FMT_C64 = 0, FMT_U8 = 1 };
+constexpr int HM_ROWS = 128;
+
+struct SpecParams {
+  const void* iq;           // float2[] or uchar2[]; frame f starts at sample f*frame_stride
+  long long frame_stride;
+  int frame_len;            // samples readable from a frame's start (range-checked by the buffer loads)
+  int nframes;
+  int nwin;
+  const int* starts;        // [nwin] sample offsets inside a frame
+  const float* window;      // [N]
+  const float2* tw_mid;     // concatenated middle-pass tables
+  const float2* tw_last;    // [15][N/16]
+  float scale;              // 2*winAdj/N
+  int cumu;
+  int out_mode;
+  float gain, min_amp;
+  float u8_offset, u8_inv_scale;
+  float* out;               // [nframes][N]
+  int hm_w;                 // 0: no waterfall row
+  const float* adj;         // [N] or null
+  float* hm_rows;           // [nframes][hm_w] or null
+  float* hm_ring;           // [128][hm_w] or null
+  int hm_index0;            // ring row of frame 0
+  int hm_first;             // first frame stored in the ring
+};
+
+__device__ __forceinline__ float db_of(float lin, float gain) { return 10.0f * log10f(lin) - gain; }
+
+// Output stage of one frame (rows A7 tail, A8, A9, A12): slot combine, 2*winAdj/N scale, fftshift,
+// LogNoGain / Clip2MinAmp, store, waterfall cell max.  red = [S][N] floats in LDS.
+template <int N, int T, int S>
+__device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, int frame, int tid) {
+  const int g = p.hm_w > 0 ? N / p.hm_w : 0;  // bins per waterfall cell
+  const bool hm_shfl = g > 0 && g <= 64 && g <= T;
+  float* const orow = p.out + (long long)frame * N;
+#pragma unroll 1
+  for (int bin = tid; bin < N; bin += T) {
+    float r = red[bin];
+    if constexpr (S > 1) {
+#pragma unroll 1
+      for (int s2 = 1; s2 < S; ++s2) {
+        const float o = red[s2 * N + bin];
+        r = p.cumu == CUMU_AVG ? r + o : p.cumu == CUMU_MAX ? fmaxf(r, o) : fminf(r, o);
+      }
+    }
+    float lin = p.cumu == CUMU_AVG ? r : __builtin_amdgcn_sqrtf(r);
+    lin *= p.scale;
+    const int sh = (bin + N / 2) & (N - 1);
+    float o = lin;
+    if (p.out_mode != OUT_LINEAR) {
+      if (p.out_mode == OUT_DB_CLIP) lin = fmaxf(lin, p.min_amp);
+      o = db_of(lin, p.gain);
+    }
+    orow[sh] = o;
+    if (g > 0) {
+      float hv = p.adj ? o - p.adj[sh] : o;
+      if (hm_shfl) {
+        // g consecutive lanes hold g consecutive bins of one cell
+        for (int m = 1; m < g; m <<= 1) hv = fmaxf(hv, __shfl_xor(hv, m));
+        if ((tid & (g - 1)) == 0) {
+          const int cell = sh / g;
+          if (p.hm_rows) p.hm_rows[(long long)frame * p.hm_w + cell] = hv;
+          if (p.hm_ring && frame >= p.hm_first)
+            p.hm_ring[((p.hm_index0 + frame) % HM_ROWS) * p.hm_w + cell] = hv;
+        }
+      } else {
+        red[S * N + sh] = hv;  // second float plane of the data region
+      }
+    }
+  }
+  if (g > 0 && !hm_shfl) {
+    __syncthreads();
+    const float* hmbuf = red + S * N;
+#pragma unroll 1
+    for (int cell = tid; cell < p.hm_w; cell += T) {
+      float hv = hmbuf[cell * g];
+      for (int i = 1; i < g; ++i) hv = fmaxf(hv, hmbuf[cell * g + i]);
+      if (p.hm_rows) p.hm_rows[(long long)frame * p.hm_w + cell] = hv;
+      if (p.hm_ring && frame >= p.hm_first)
+        p.hm_ring[((p.hm_index0 + frame) % HM_ROWS) * p.hm_w + cell] = hv;
+    }
+  }
+}
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int N, int FMT>
+__global__ __launch_bounds__(Plan<N>::T, 4) void spectrum_kernel(const SpecParams p) {
+  using P = Plan<N>;
+  constexpr int L = P::L, T = P::T, S = P::S, M = P::M, R0 = P::R0, B0 = P::B0, NPAD = P::NPAD;
+  constexpr int SB = FMT == FMT_C64 ? 8 : 2;  // bytes per IQ sample
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  float2* const tw_lds = lds + S * NPAD;
+
+  const int tid = threadIdx.x;
+  const int slot = tid / L;
+  const int l = tid - slot * L;
+  float2* const my = lds + slot * NPAD;
+
+  // ---- per-thread constants: window taps and last-pass twiddles stay in VGPRs ----------------
+  float win[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) win[q] = p.window[l + L * q];
+  float wof[16];  // only live for the uint8 format
+  if constexpr (FMT == FMT_U8) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      wof[q] = -win[q] * p.u8_offset * p.u8_inv_scale;
+      win[q] = win[q] * p.u8_inv_scale;
+    }
+  }
+  // last pass: k = l, twiddle base w = e^{-2*pi*i*l/N}; rows t = 1,2,3,4,8,12 of the [15][N/16] table
+  float2 w1, w2, w3, w4, w8, w12;
+  if constexpr (M >= 2) {
+    w1 = p.tw_last[0 * P::P_LAST + l];
+    w2 = p.tw_last[1 * P::P_LAST + l];
+    w3 = p.tw_last[2 * P::P_LAST + l];
+    w4 = p.tw_last[3 * P::P_LAST + l];
+    w8 = p.tw_last[7 * P::P_LAST + l];
+    w12 = p.tw_last[11 * P::P_LAST + l];
+  }
+  if constexpr (P::MID > 0) {
+    for (int i = tid; i < P::MID; i += T) tw_lds[i] = p.tw_mid[i];
+  }
+
+  const int rounds = (p.nwin + S - 1) / S;
+  const int nm1 = p.nwin - 1;
+
+  for (int frame = blockIdx.x; frame < p.nframes; frame += gridDim.x) {
+    float acc[16];
+    const float init = p.cumu == CUMU_MIN ? __builtin_inff() : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = init;
+    // one buffer descriptor per frame: wave-uniform base, hardware range check on every load
+    const char* fbase = reinterpret_cast<const char*>(p.iq) + (long long)frame * p.frame_stride * SB;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fbase), 0, p.frame_len * SB, 0x00020000);
+
+    for (int rd = 0; rd < rounds; ++rd) {
+      const int k = rd * S + slot;
+      const bool active = S == 1 || k < p.nwin;
+      float2 v[16];
+      if (active) {
+        const int voff = (p.starts[k] + l) * SB;
+        if constexpr (FMT == FMT_C64) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, L * q * SB, 0);
+            // (scalar copies first: __builtin_bit_cast on a vector element reads element 0 twice)
+            const unsigned xr = x.x, xi = x.y;
+            v[(q % B0) * R0 + (q / B0)] = make_float2(__uint_as_float(xr) * win[q], __uint_as_float(xi) * win[q]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const unsigned short x = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, L * q * SB, 0);
+            v[(q % B0) * R0 + (q / B0)] = make_float2(fmaf((float)(x & 0xff), win[q], wof[q]),
+                                                      fmaf((float)(x >> 8), win[q], wof[q]));
+          }
+        }
+        dft_first<R0>(v);
+      }
+      if constexpr (M >= 2) {
+        __syncthreads();  // previous round's / frame's LDS reads are done
+        if (active) {
+#pragma unroll
+          for (int b = 0; b < B0; ++b) {
+            const int i = l + b * L;  // butterfly index, p = 1
+#pragma unroll
+            for (int t = 0; t < R0; ++t) my[padi(i * R0 + perm<R0>(t))] = v[b * R0 + t];
+          }
+        }
+        __syncthreads();
+        int pp = R0;       // product of the radices already applied
+        int tw_off = 0;
+#pragma unroll
+        for (int s = 1; s < M; ++s) {
+          if (active) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = my[padi(l + L * t)];
+            if (s < M - 1) {
+              const float2* tw = tw_lds + tw_off + (l & (pp - 1));
+              dft16_tw(v, tw[0], tw[pp], tw[2 * pp], tw[3 * pp], tw[7 * pp], tw[11 * pp]);
+            } else {
+              dft16_tw(v, w1, w2, w3, w4, w8, w12);
+            }
+          }
+          if (s < M - 1) {
+            __syncthreads();
+            if (active) {
+              const int kk = l & (pp - 1);
+              const int j = (l - kk) * 16 + kk;
+#pragma unroll
+              for (int t = 0; t < 16; ++t) my[padi(j + perm<16>(t) * pp)] = v[t];
+            }
+            __syncthreads();
+            tw_off += 15 * pp;
+            pp *= 16;
+          }
+        }
+      }
+      // ---- |X| and the fold over this block's windows (K:391-395) ----------------------------
+      if (active) {
+        if (p.cumu == CUMU_AVG) {
+          // closed form of the (a+x)/2 recursion: weight 2^-(n-k+1), first window 2^-n
+          const int e = k == 0 ? nm1 : nm1 - k + 1;
+          const float w = ldexpf(1.0f, -e);
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            acc[i] = fmaf(w, __builtin_amdgcn_sqrtf(fmaf(v[i].x, v[i].x, v[i].y * v[i].y)), acc[i]);
+        } else if (p.cumu == CUMU_MAX) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = fminf(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
+        }
+      }
+    }
+
+    // ---- combine the slots, scale, fftshift, dB, waterfall row ------------------------------
+    // register position i of thread (slot,l) is bin l + L*perm16(i)   (M == 1: N == 16, L == 1).
+    // The fold result goes through LDS once per frame so that the (rolled, branchy) output stage
+    // does not share registers with the transform loop.
+    float* const red = reinterpret_cast<float*>(lds);  // [S][N] floats, inside the data region
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[slot * N + l + L * perm<16>(i)] = acc[i];
+    __syncthreads();
+    finish_frame<N, T, S>(p, red, frame, tid);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// zeroSpanPlay: dB + waterfall row of spectra that are already linear magnitudes (K:469, K:480)
+struct DbRowParams {
+  const float* lin;  // [nframes][N]
+  float* out;        // [nframes][N] dB
+  int n, nframes;
+  float gain;
+  int hm_w;
+  const float* adj;
+  float* hm_rows;
+  float* hm_ring;
+  int hm_index0, hm_first;
+};
+
+__global__ void db_rows_kernel(const DbRowParams p) {
+  const int frame = blockIdx.y;
+  const int g = p.hm_w > 0 ? p.n / p.hm_w : 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += gridDim.x * blockDim.x)
+    p.out[(long long)frame * p.n + i] = db_of(p.lin[(long long)frame * p.n + i], p.gain);
+  if (g == 0) return;
+  for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < p.hm_w; cell += gridDim.x * blockDim.x) {
+    float hv = -__builtin_inff();
+    bool nan = false;
+    for (int i = 0; i < g; ++i) {
+      const int b = cell * g + i;
+      float v = db_of(p.lin[(long long)frame * p.n + b], p.gain);
+      if (p.adj) v -= p.adj[b];
+      nan |= v != v;
+      hv = fmaxf(hv, v);
+    }
+    if (nan) hv = __builtin_nanf("");
+    if (p.hm_rows) p.hm_rows[(long long)frame * p.hm_w + cell] = hv;
+    if (p.hm_ring && frame >= p.hm_first)
+      p.hm_ring[((p.hm_index0 + frame) % HM_ROWS) * p.hm_w + cell] = hv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row A10.  Max / Min are elementwise; Avg is the closed form of the reference's EMA:
+// after frames 0..n:  avg = x0*2^-n + sum_{k>=1} x_k*2^-(n-k+1)   (K:137-139 applied at K:476).
+// Non-finite terms (the -inf of a zero magnitude, K:469) poison the sum whatever their weight,
+// as they do in the recursion.
+struct AccParams {
+  const float* db;   // [nframes][N]
+  int n, nframes;
+  long long first_index, total_frames;  // position of this batch in the logical run
+  int has_prev;      // state already holds frames
+  int chunk;         // frames per partial
+  float* part;       // [chunks][3][N] : max, min, sum
+};
+
+__device__ __forceinline__ float nan_max(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
+__device__ __forceinline__ float nan_min(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fminf(a, b); }
+
+__global__ void accumulate_partial_kernel(const AccParams p) {
+  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= p.n) return;
+  const int c = blockIdx.y;
+  const int f0 = c * p.chunk;
+  const int f1 = min(p.nframes, f0 + p.chunk);
+  float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.f;
+  for (int f = f0; f < f1; ++f) {
+    const float x = p.db[(long long)f * p.n + bin];
+    mx = nan_max(mx, x);
+    mn = nan_min(mn, x);
+    const long long kg = p.first_index + f;
+    long long e = p.total_frames - kg;            // 2^-(n-k+1) with n = total-1
+    if (kg == 0 && !p.has_prev) e = p.total_frames - 1;
+    const float w = e > 160 ? 0.f : ldexpf(1.0f, -(int)e);
+    const bool fin = fabsf(x) < __builtin_inff();
+    sum += fin ? w * x : x;
+  }
+  float* o = p.part + (long long)c * 3 * p.n;
+  o[bin] = mx;
+  o[p.n + bin] = mn;
+  o[2 * p.n + bin] = sum;
+}
+
+// partial block layout: [max | cur-or--inf | min | sum], N floats each
+__global__ void accumulate_reduce_kernel(const float* part, int chunks, int n, const float* last_db,
+                                         int owns_last, float* partial) {
+  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= n) return;
+  float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    const float* o = part + (long long)c * 3 * n;
+    mx = nan_max(mx, o[bin]);
+    mn = nan_min(mn, o[n + bin]);
+    sum += o[2 * n + bin];
+  }
+  partial[bin] = mx;
+  partial[n + bin] = owns_last ? last_db[bin] : -__builtin_inff();
+  partial[2 * n + bin] = mn;
+  partial[3 * n + bin] = sum;
+}
+
+// state layout: [cur | max | min | avg]
+__global__ void commit_kernel(const float* partial, float* state, int n, int has_prev,
+                              long long total_frames, int b_max, int b_min, int b_avg) {
+  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= n) return;
+  const float mx = partial[bin], cur = partial[n + bin], mn = partial[2 * n + bin], sum = partial[3 * n + bin];
+  state[bin] = cur;
+  if (b_max) state[n + bin] = has_prev ? nan_max(state[n + bin], mx) : mx;
+  if (b_min) state[2 * n + bin] = has_prev ? nan_min(state[2 * n + bin], mn) : mn;
+  if (b_avg) {
+    float a = sum;
+    if (has_prev) {
+      const float prev = state[3 * n + bin];
+      const float w = total_frames > 160 ? 0.f : ldexpf(1.0f, -(int)total_frames);
+      a += (fabsf(prev) < __builtin_inff()) ? prev * w : prev;
+    }
+    state[3 * n + bin] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row A13.  Element e of the stitched range is covered by the steps i with i*hop <= e < i*hop + N.
+// The reference copies the first covering step (RAW, K:644) and halves-in every later one (AVG,
+// K:649); after the last covering step the value is final and is what Max/Min/Avg see (K:657-668).
+struct StitchParams {
+  const float* step_db;  // [nsteps][N]
+  int n, nsteps, hop, total;
+  float* state;          // [4][total] : cur, max, min, avg
+  int first_pass;        // pass 0 seeds Avg by copy (K:615-618)
+  int b_max, b_min;
+};
+
+__global__ void scan_stitch_kernel(const StitchParams p) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.total) return;
+  int i0 = (e - p.n + p.hop) / p.hop;  // ceil((e-n+1)/hop) for e-n+1 > 0
+  if (e - p.n + 1 <= 0) i0 = 0;
+  int i1 = e / p.hop;
+  if (i1 > p.nsteps - 1) i1 = p.nsteps - 1;
+  if (i0 > i1) return;                 // not covered this pass: state keeps its value
+  float cur = p.step_db[(long long)i0 * p.n + (e - i0 * p.hop)];
+  for (int i = i0 + 1; i <= i1; ++i) cur = (cur + p.step_db[(long long)i * p.n + (e - i * p.hop)]) * 0.5f;
+  const int tot = p.total;
+  p.state[e] = cur;
+  if (p.b_max) p.state[tot + e] = nan_max(p.state[tot + e], cur);
+  if (p.b_min) p.state[2 * tot + e] = nan_min(p.state[2 * tot + e], cur);
+  p.state[3 * tot + e] = p.first_pass ? cur : (p.state[3 * tot + e] + cur) * 0.5f;
+}
+
+__global__ void fill_kernel(float* dst, long long n, float v) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+// out[c] = max_{i<g} (src[c*g+i] - adj[c*g+i])
+__global__ void rowmax_kernel(const float* src, const float* adj, int cells, int g, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cells) return;
+  float hv = -__builtin_inff();
+  bool nan = false;
+  for (int i = 0; i < g; ++i) {
+    float v = src[(long long)c * g + i];
+    if (adj) v -= adj[(long long)c * g + i];
+    nan |= v != v;
+    hv = fmaxf(hv, v);
+  }
+  out[c] = nan ? __builtin_nanf("") : hv;
+}
+
+}  // namespace ksa

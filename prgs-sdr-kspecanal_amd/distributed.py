@@ -1,0 +1,87 @@
+"""Time-chunk sharding of a zeroSpan run over the GPUs of one node (one process per GPU, RCCL).
+
+The reference's frame loop (python/kspecanal.py:460-484) is sequential only through its accumulators.
+Frames are independent up to the dB spectrum, so rank r takes frames [r*F, (r+1)*F) of a run of
+G*F frames and the accumulators are merged with the algebra of SURVEY.md 8(e):
+
+  Max, Min  -> elementwise all-reduce MAX / MIN
+  Avg       -> the (a+x)/2 recursion (K:137-139) in closed form is sum_k 2^-(n-k+1) x_k; every rank sums
+               its frames with their GLOBAL weights (libksa does that given first_index/total_frames), then
+               one all-reduce SUM
+  Cur       -> the globally last frame: -inf on every other rank, merged by the MAX all-reduce
+  waterfall -> the ring keeps the last 128 rows of the run; every rank writes its rows at the globally
+               correct ring slots, one all-gather picks each slot from the rank that owns its newest frame.
+
+Message sizes are a few KiB..MiB (latency bound on xGMI), so the collectives are fused: one MAX over
+[max|cur], one MIN, one SUM, one all-gather -- per batch, not per frame.
+The tensor algebra below is device agnostic (tested on CPU with gloo, run on GPUs with nccl = RCCL).
+"""
+import torch
+import torch.distributed as dist
+
+HM_ROWS = 128
+
+
+def merge_partials(partial, group=None):
+    """partial: float32[4, N] = {max, cur-or--inf, min, weighted sum} of this rank's chunk, in place."""
+    dist.all_reduce(partial[0:2], op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(partial[2], op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(partial[3], op=dist.ReduceOp.SUM, group=group)
+    return partial
+
+
+def ring_owner(idx0, frames_per_rank, world):
+    """For every ring slot: the rank whose chunk holds the newest frame stored there, or -1 if no frame of
+    this run maps to the slot within the last 128 frames.  Global frame g lives in slot (idx0+g) % 128."""
+    total = frames_per_rank * world
+    slots = torch.arange(HM_ROWS)
+    # newest g < total with (idx0 + g) % 128 == slot
+    last = total - 1
+    back = (idx0 + last - slots) % HM_ROWS
+    g = last - back
+    owner = torch.where(g >= 0, g // max(frames_per_rank, 1), torch.full_like(g, -1))
+    return owner
+
+
+def merge_ring(ring, idx0, frames_per_rank, world, group=None):
+    """ring: float32[128, W] of this rank (rows written at globally correct slots), merged in place."""
+    if world == 1:
+        return ring
+    gathered = [torch.empty_like(ring) for _ in range(world)]
+    dist.all_gather(gathered, ring.contiguous(), group=group)
+    owner = ring_owner(idx0, frames_per_rank, world).to(ring.device)
+    stack = torch.stack(gathered)                       # [world, 128, W]
+    pick = owner.clamp(min=0).view(1, HM_ROWS, 1).expand(1, HM_ROWS, ring.shape[1])
+    merged = torch.gather(stack, 0, pick)[0]
+    keep = (owner < 0).view(HM_ROWS, 1)
+    ring.copy_(torch.where(keep, ring, merged))
+    return ring
+
+
+class ShardedZeroSpan:
+    """Drives one engine per rank; with world == 1 it is a plain frames_dev call."""
+
+    def __init__(self, engine, rank=0, world=1, group=None):
+        self.eng, self.rank, self.world, self.group = engine, rank, world, group
+        self.hm_index = 0                              # global ring position (identical on all ranks)
+        if world > 1:
+            self._partial = torch.as_tensor(engine.partial(), device="cuda")
+            _, ring = engine.state_dev()
+            self._ring = torch.as_tensor(ring, device="cuda")
+
+    def step(self, iq, fmt, frames, cur_db=None, hm_rows=None):
+        """Every rank passes its own `frames` capture blocks (its time chunk of a world*frames run)."""
+        eng = self.eng
+        if self.world == 1:
+            eng.frames_dev(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
+            self.hm_index = (self.hm_index + frames) % HM_ROWS
+            return
+        total = frames * self.world
+        eng.set_hm_index((self.hm_index + self.rank * frames) % HM_ROWS)
+        eng.frames_dev(iq, fmt, frames, first_index=self.rank * frames, total_frames=total,
+                       cur_db=cur_db, hm_rows=hm_rows, commit=False)
+        merge_partials(self._partial, self.group)
+        eng.commit(total)
+        merge_ring(self._ring, self.hm_index, frames, self.world, self.group)
+        self.hm_index = (self.hm_index + total) % HM_ROWS
+        eng.set_hm_index(self.hm_index)

@@ -1,0 +1,276 @@
+"""Host side of the spectrum engine: reference-compatible geometry + the ctypes calls.
+
+Everything numeric happens in libksa.so on the GPU.  What stays here is what the reference also
+does once per run on the host (python/kspecanal.py, "K:"): the capture-block size (K:926-929), the
+window table and its amplitude compensation (K:932-936, K:373), the window start offsets with the
+reference's float64 truncation (K:368, K:386-390) and the waterfall width rule (K:449-455).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, Config, CUMU, FMT_C64, FMT_U8, OUT_LINEAR, OUT_DB, OUT_DB_CLIP, HM_ROWS, KsaError
+
+MIN_AMP_DEFAULT = (1 / 256) * 0.00001   # gMinAmp4Clip K:53
+FFT2FULL_LESS, FFT2FULL_MORE = 8, 2     # K:49-50
+
+
+def full_size_for(fft_size, sampling_rate):
+    """K:926-929."""
+    return fft_size * FFT2FULL_LESS if fft_size < (sampling_rate // 8) else fft_size * FFT2FULL_MORE
+
+
+def window_starts(full_size, fft_size, non_overlap):
+    """K:368 + K:386-390, evaluated exactly like the reference (float64 product, int() truncation)."""
+    num_loops = int(full_size / (fft_size * non_overlap))
+    starts = []
+    for i in range(num_loops):
+        s = int(i * fft_size * non_overlap)
+        if s + fft_size > full_size:
+            break
+        starts.append(s)
+    if not starts:
+        raise KsaError("no complete window fits: fullSize %d fftSize %d" % (full_size, fft_size))
+    return np.asarray(starts, dtype=np.int32)
+
+
+def window_table(name, n):
+    """K:932-935; accepts the CLI spelling or the 'WIN.X' dict key of the reference."""
+    key = name.upper().replace("WIN.", "")
+    if key == "ONES":
+        return np.ones(n)
+    if key == "HANNING":
+        return np.hanning(n)
+    if key == "HAMMING":
+        return np.hamming(n)
+    if key == "KAISER":
+        return np.kaiser(n, 64)
+    raise KsaError("unknown window [%s]" % name)
+
+
+def heatmap_width(fft_size, xres):
+    """K:449-455 with pltCompressHM = MAX (K:67)."""
+    return xres if fft_size > xres else fft_size
+
+
+def _ptr(a):
+    """Device/host address of a torch tensor, numpy array, ctypes pointer or int."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return a
+
+
+class DevArray:
+    """View of library-owned device memory for torch.as_tensor (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr, shape, owner):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class SpectrumEngine:
+    """One GPU's engine for one (fftSize, window, overlap, mode) configuration."""
+
+    def __init__(self, fft_size, full_size=None, sampling_rate=2.4e6, non_overlap=0.1, window="ones",
+                 cumu_mode="AVG", gain=19.1, min_amp=MIN_AMP_DEFAULT, xres=512, max_frames=1, device=0,
+                 scan_total_entries=0, scan_non_overlap=0.5, scan_xres=None,
+                 u8_offset=127.5, u8_scale=127.5, stream=None):
+        self.fft_size = int(fft_size)
+        self.full_size = int(full_size) if full_size is not None else full_size_for(self.fft_size, sampling_rate)
+        self.non_overlap = float(non_overlap)
+        self.cumu_mode = cumu_mode.upper()
+        if self.cumu_mode not in CUMU:
+            raise KsaError("unknown cumuMode [%s]" % cumu_mode)
+        self.gain = float(gain)
+        self.min_amp = float(min_amp)
+        self.max_frames = int(max_frames)
+        self.device = int(device)
+        win = window_table(window, self.fft_size) if isinstance(window, str) else np.asarray(window, dtype=np.float64)
+        if len(win) != self.fft_size:
+            raise KsaError("window table has %d taps, fftSize is %d" % (len(win), self.fft_size))
+        self.win = win
+        self.win_adj = len(win) / np.sum(win)                      # K:373
+        self.starts = window_starts(self.full_size, self.fft_size, self.non_overlap)
+        self.hm_width = heatmap_width(self.fft_size, int(xres))
+        if self.fft_size % self.hm_width:
+            raise KsaError("xRes %d does not divide fftSize %d (the reference fixes xRes up at K:937-949)" % (xres, fft_size))
+        self.scan_total = int(scan_total_entries)
+        self.scan_hop = 0
+        self.scan_hm_width = 0
+        if self.scan_total:
+            hop = self.fft_size * scan_non_overlap
+            if hop % 1 != 0:                                       # K:591-593
+                raise KsaError("fftSize[%d] x scanRangeNonOverlap [%s] is not int" % (self.fft_size, scan_non_overlap))
+            self.scan_hop = int(hop)
+            self.scan_hm_width = int(scan_xres if scan_xres is not None else xres)
+        self._starts32 = np.ascontiguousarray(self.starts, dtype=np.int32)
+        self._win32 = np.ascontiguousarray(win, dtype=np.float32)
+        cfg = Config(
+            abi_version=_lib.ABI_VERSION, device=self.device, fft_size=self.fft_size, full_size=self.full_size,
+            num_windows=len(self._starts32),
+            window_starts=self._starts32.ctypes.data_as(C.POINTER(C.c_int32)),
+            window=self._win32.ctypes.data_as(C.POINTER(C.c_float)),
+            mag_scale=2.0 * self.win_adj / self.fft_size,          # K:391
+            cumu_mode=CUMU[self.cumu_mode], gain=self.gain, min_amp=self.min_amp, hm_width=self.hm_width,
+            max_frames=self.max_frames, u8_offset=u8_offset, u8_scale=u8_scale,
+            scan_total_entries=self.scan_total, scan_hop=self.scan_hop, scan_hm_width=self.scan_hm_width)
+        h = C.c_void_p()
+        check(lib.ksa_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.ksa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream):
+        """stream: a hipStream_t as int (torch.cuda.current_stream().cuda_stream) or None."""
+        check(lib.ksa_set_stream(self._h, C.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        check(lib.ksa_synchronize(self._h))
+
+    @property
+    def num_windows(self):
+        return len(self.starts)
+
+    def kernel_info(self):
+        v = [C.c_int32() for _ in range(5)]
+        check(lib.ksa_kernel_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("threads", "lds_bytes", "vgprs", "grid", "path"), [x.value for x in v]))
+
+    # -- sdr_curscan drop-in (K:351-397) ---------------------------------------------------------
+    def _host_iq(self, samples):
+        a = np.asarray(samples)
+        if a.dtype == np.uint8:
+            if a.size != 2 * self.full_size:
+                raise KsaError("uint8 block has %d bytes, need %d" % (a.size, 2 * self.full_size))
+            return np.ascontiguousarray(a), FMT_U8
+        if a.size != self.full_size:
+            raise KsaError("block has %d samples, fullSize is %d" % (a.size, self.full_size))
+        return np.ascontiguousarray(a, dtype=np.complex64), FMT_C64
+
+    def curscan(self, samples):
+        """One captured block -> float64[fftSize] linear magnitudes, fftshifted (what sdr_curscan returns)."""
+        a, fmt = self._host_iq(samples)
+        out = np.empty(self.fft_size, dtype=np.float32)
+        fn = lib.ksa_curscan_u8 if fmt == FMT_U8 else lib.ksa_curscan_c64
+        check(fn(self._h, _ptr(a), _ptr(out)))
+        return out.astype(np.float64)
+
+    def curscan_dev(self, iq, fmt, nframes, out, out_mode=OUT_LINEAR, frame_stride=None):
+        stride = self.full_size if frame_stride is None else int(frame_stride)
+        check(lib.ksa_curscan_dev(self._h, _ptr(iq), fmt, stride, int(nframes), out_mode, _ptr(out)))
+
+    # -- zeroSpan frame loop body (K:464-484) ------------------------------------------------------
+    def frame(self, samples):
+        a, fmt = self._host_iq(samples)
+        fn = lib.ksa_frame_u8 if fmt == FMT_U8 else lib.ksa_frame_c64
+        check(fn(self._h, _ptr(a)))
+
+    def frame_spectrum(self, mag):
+        a = np.ascontiguousarray(mag, dtype=np.float32)
+        if a.size != self.fft_size:
+            raise KsaError("spectrum has %d bins, fftSize is %d" % (a.size, self.fft_size))
+        check(lib.ksa_frame_spectrum(self._h, _ptr(a)))
+
+    def frames_dev(self, iq, fmt, nframes, first_index=0, total_frames=None, cur_db=None, hm_rows=None,
+                   commit=True, frame_stride=None):
+        stride = self.full_size if frame_stride is None else int(frame_stride)
+        total = int(nframes) if total_frames is None else int(total_frames)
+        check(lib.ksa_frames_dev(self._h, _ptr(iq), fmt, stride, int(nframes), int(first_index), total,
+                                 _ptr(cur_db), _ptr(hm_rows), 1 if commit else 0))
+
+    def partial(self):
+        """Device view float32[4, N] = {max, cur-or--inf, min, weighted sum} of the uncommitted batch."""
+        p = C.c_void_p()
+        check(lib.ksa_partial_dev(self._h, C.byref(p)))
+        return DevArray(p.value, (4, self.fft_size), self)
+
+    def commit(self, total_frames):
+        check(lib.ksa_commit(self._h, int(total_frames)))
+
+    def set_flags(self, b_max=True, b_min=True, b_avg=True):
+        check(lib.ksa_set_flags(self._h, int(b_max), int(b_min), int(b_avg)))
+
+    def set_adj(self, adj):
+        if adj is None:
+            check(lib.ksa_set_adj(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(adj, dtype=np.float32)
+        check(lib.ksa_set_adj(self._h, _ptr(a), a.size))
+
+    def reset(self):
+        check(lib.ksa_reset_state(self._h))
+
+    def state(self):
+        """The plotting hand-off of the reference: d['Fft.Cur'|'Fft.Max'|'Fft.Min'|'Fft.Avg'] as
+        float64[N] (K:470-476) and the waterfall buffer fed to hm.set_data (K:481)."""
+        n = self.fft_size
+        bufs = [np.empty(n, dtype=np.float32) for _ in range(4)]
+        hm = np.empty((HM_ROWS, self.hm_width), dtype=np.float32)
+        idx, seen = C.c_int32(), C.c_int64()
+        check(lib.ksa_read_state(self._h, *[_ptr(b) for b in bufs], _ptr(hm), C.byref(idx), C.byref(seen)))
+        out = {"Fft.Cur": bufs[0], "Fft.Max": bufs[1], "Fft.Min": bufs[2], "Fft.Avg": bufs[3]}
+        out = {k: v.astype(np.float64) for k, v in out.items()}
+        out.update(fftHM=hm.astype(np.float64), hm_index=idx.value, frames=seen.value)
+        return out
+
+    def state_dev(self):
+        s, h = C.c_void_p(), C.c_void_p()
+        check(lib.ksa_state_dev(self._h, C.byref(s), C.byref(h)))
+        return DevArray(s.value, (4, self.fft_size), self), DevArray(h.value, (HM_ROWS, self.hm_width), self)
+
+    def set_hm_index(self, i):
+        check(lib.ksa_set_hm_index(self._h, int(i)))
+
+    # -- scan (K:621-668, K:696-697) ----------------------------------------------------------------
+    def scan_pass_dev(self, iq, fmt, nsteps, step_ok=None, frame_stride=None):
+        stride = self.full_size if frame_stride is None else int(frame_stride)
+        ok = None
+        if step_ok is not None:
+            ok = np.ascontiguousarray(step_ok, dtype=np.uint8)
+        check(lib.ksa_scan_pass_dev(self._h, _ptr(iq), fmt, stride, int(nsteps), _ptr(ok)))
+
+    def scan_stitch_dev(self, step_db, nsteps):
+        check(lib.ksa_scan_stitch_dev(self._h, _ptr(step_db), int(nsteps)))
+
+    def scan_state(self):
+        t = self.scan_total
+        bufs = [np.empty(t, dtype=np.float32) for _ in range(4)]
+        hm = np.empty((HM_ROWS, self.scan_hm_width), dtype=np.float32)
+        idx, passes = C.c_int32(), C.c_int64()
+        check(lib.ksa_scan_read_state(self._h, *[_ptr(b) for b in bufs], _ptr(hm), C.byref(idx), C.byref(passes)))
+        out = {"Fft.Cur": bufs[0], "Fft.Max": bufs[1], "Fft.Min": bufs[2], "Fft.Avg": bufs[3]}
+        out = {k: v.astype(np.float64) for k, v in out.items()}
+        out.update(fftHM=hm.astype(np.float64), hm_index=idx.value, passes=passes.value)
+        return out
+
+    def scan_reset(self):
+        check(lib.ksa_scan_reset(self._h))
+
+    # -- measurement ------------------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(lib.ksa_prof_enable(self._h, int(on)))
+
+    def prof_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        check(lib.ksa_prof_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

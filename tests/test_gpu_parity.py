@@ -1,0 +1,308 @@
+"""GPU parity: libksa (through the C ABI) against the oracle and the reference-generated golden
+vectors.  Run on the MI355X box with `pytest -m gpu`.
+
+Tolerances (fp32 device arithmetic vs the float64 reference):
+  * linear spectra: max|got - want| / max|want| <= 1e-5   (BASELINE.json north_star)
+  * dB curves: compared in the linear domain by the same rule (10**(dB/10)), plus an absolute
+    5e-3 dB bound on bins within 60 dB of the peak (near-zero bins have unbounded relative error).
+"""
+import numpy as np
+import pytest
+
+import ksa_oracle as orc
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+WINDOWS = ("ones", "hanning", "hamming", "kaiser")
+MODES = ("AVG", "MAX", "MIN", "RAW")
+GAIN = 19.1
+
+
+def nerr(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    return float(np.max(np.abs(np.asarray(got, dtype=np.float64) - want)) / np.max(np.abs(want)))
+
+
+def assert_lin(got, want, tol=1e-5, what=""):
+    e = nerr(got, want)
+    assert e <= tol, "%s normalised error %.3g > %.3g" % (what, e, tol)
+
+
+def assert_db(got, want, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isneginf(got), np.isneginf(want)), what + " -inf pattern"
+    assert_lin(10 ** (got[fin] / 10), 10 ** (want[fin] / 10), what=what)
+    strong = fin & (want > np.max(want[fin]) - 60)
+    d = np.max(np.abs(got[strong] - want[strong]))
+    assert d <= 5e-3, "%s dB error %.3g" % (what, d)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+# ------------------------------------------------------------------------------------------ curscan
+@pytest.mark.parametrize("tag", ["n64_q01", "n512_q01", "n512_q05", "n4096_q05"])
+def test_curscan_vs_reference_golden(ksa, tag):
+    g = golden("curscan_" + tag)
+    n, q, full = int(g["fft_size"]), float(g["non_overlap"]), int(g["full"])
+    checked = 0
+    for w in WINDOWS:
+        for m in MODES:
+            key = "%s_%s" % (w, m)
+            if key not in g.files:
+                continue
+            eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=w, cumu_mode=m)
+            assert_lin(eng.curscan(g["iq"]), g[key], what=tag + " " + key)
+            eng.close()
+            checked += 1
+    assert checked >= 6
+
+
+@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("q", [0.5, 0.1])
+def test_curscan_every_plan_size(ksa, n, q):
+    full = orc.full_size(n, 2.4e6)
+    x = orc.synth_iq(full, 1000 + n).astype(np.complex64)
+    for w, m in (("hanning", "AVG"), ("kaiser", "MAX"), ("ones", "MIN")):
+        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=w, cumu_mode=m)
+        assert eng.num_windows == len(orc.window_starts(full, n, q))
+        want = orc.curscan(x, n, q, orc.window_table(w, n), m)
+        assert_lin(eng.curscan(x), want, what="N=%d q=%s %s %s" % (n, q, w, m))
+        eng.close()
+
+
+@pytest.mark.parametrize("tag", ["n8192_q05", "n16384_q01"])
+def test_curscan_large_n_golden(ksa, tag):
+    g = golden("curscan_" + tag)
+    n, q, full = int(g["fft_size"]), float(g["non_overlap"]), int(g["full"])
+    x = orc.synth_iq(full, int(g["seed"])).astype(np.complex64)
+    for mode, key, dec in (("AVG", "avg_at_idx", "avg_decim"), ("MAX", "max_at_idx", "max_decim")):
+        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=str(g["window"]), cumu_mode=mode)
+        y = eng.curscan(x)
+        peak = float(g["peak"])
+        assert np.max(np.abs(y[g["idx"]] - g[key])) / peak <= 1e-5
+        red = y.reshape(256, -1).sum(axis=1) if mode == "AVG" else y.reshape(256, -1).max(axis=1)
+        assert np.max(np.abs(red - g[dec])) / np.max(g[dec]) <= 1e-5
+        eng.close()
+
+
+def test_on_bin_tone_known_answer(ksa):
+    g = golden("tone_n4096")
+    for w in WINDOWS:
+        eng = ksa.SpectrumEngine(4096, full_size=32768, non_overlap=0.5, window=w)
+        y = eng.curscan(g["iq"])
+        assert int(np.argmax(y)) == 2560 and abs(y[2560] - 1.0) < 1e-5
+        assert_lin(y, g[w], what="tone " + w)
+        eng.close()
+
+
+@pytest.mark.parametrize("n,q", [(64, 0.1), (512, 0.5), (4096, 0.5), (16384, 0.1)])
+def test_curscan_uint8_input(ksa, n, q):
+    full = orc.full_size(n, 2.4e6)
+    raw = orc.quantize_u8(orc.synth_iq(full, 77 + n) * 0.8)
+    want = orc.curscan(orc.unpack_u8(raw), n, q, orc.window_table("hanning", n), "AVG")
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning")
+    assert_lin(eng.curscan(raw), want, what="u8 N=%d" % n)
+    eng.close()
+
+
+def test_bad_arguments_raise(ksa):
+    with pytest.raises(ksa.KsaError):
+        ksa.SpectrumEngine(1000)                       # not a power of two
+    with pytest.raises(ksa.KsaError):
+        ksa.SpectrumEngine(4096, window="blackman")
+    with pytest.raises(ksa.KsaError):
+        ksa.SpectrumEngine(4096, cumu_mode="MEDIAN")
+    eng = ksa.SpectrumEngine(512, non_overlap=0.5)
+    with pytest.raises(ksa.KsaError):
+        eng.curscan(np.zeros(100, dtype=np.complex64))  # ragged block
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------- zeroSpan state
+@pytest.mark.parametrize("tag", ["n512", "n4096", "n64", "hm_n512"])
+def test_zerospan_frames_vs_reference_golden(ksa, tag):
+    g = golden("zerospan_" + tag)
+    n, q, full, frames = int(g["fft_size"]), float(g["non_overlap"]), int(g["full"]), int(g["frames"])
+    x = g["iq"].reshape(frames, full)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=str(g["window"]),
+                             gain=float(g["gain"]), xres=int(g["xres"]))
+    for f in range(frames):
+        eng.frame(x[f])
+    st = eng.state()
+    assert st["frames"] == frames and st["hm_index"] == frames % 128
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], g[k], what=tag + " " + k)
+    if "hm" in g.files:
+        want = g["hm"]
+        assert st["fftHM"].shape == want.shape
+        assert_db(st["fftHM"][:frames], want[:frames], what=tag + " hm")
+        assert np.all(st["fftHM"][frames:] == 0)     # untouched rows keep np.zeros (K:456)
+    eng.close()
+
+
+@pytest.mark.parametrize("n,q,fmt", [(4096, 0.5, "c64"), (512, 0.1, "c64"), (64, 0.1, "u8"), (2048, 0.5, "u8")])
+def test_zerospan_batched_device_path(ksa, torch_cuda, n, q, fmt):
+    """frames_dev over a batch == the oracle's sequential loop, incl. a second batch on top (EMA carry)."""
+    torch = torch_cuda
+    full = orc.full_size(n, 2.4e6)
+    f1, f2 = 37, 150
+    x = orc.synth_iq(full * (f1 + f2), 5 + n).astype(np.complex64).reshape(f1 + f2, full)
+    if fmt == "u8":
+        raw = orc.quantize_u8(x.reshape(-1) * 0.8).reshape(f1 + f2, 2 * full)
+        host, xin = raw, orc.unpack_u8(raw.reshape(-1)).reshape(f1 + f2, full)
+        dev = torch.from_numpy(raw).cuda()
+        code = ksa.FMT_U8
+    else:
+        xin = x
+        dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+        code = ksa.FMT_C64
+    win = orc.window_table("hanning", n)
+    st_ref, db_ref, _ = orc.zerospan_batch(xin, n, q, win, "AVG", GAIN, 512)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning", gain=GAIN, max_frames=f2)
+    cur_db = torch.empty((f2, n), dtype=torch.float32, device="cuda")
+    rows = torch.empty((f2, eng.hm_width), dtype=torch.float32, device="cuda")
+    eng.frames_dev(dev[:f1], code, f1, cur_db=cur_db, hm_rows=rows)
+    eng.frames_dev(dev[f1:], code, f2, cur_db=cur_db, hm_rows=rows)
+    torch.cuda.synchronize()
+    st = eng.state()
+    assert st["frames"] == f1 + f2 and st["hm_index"] == (f1 + f2) % 128
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], getattr(st_ref, k), what="N=%d %s" % (n, k))
+    assert_db(cur_db.cpu().numpy(), db_ref[f1:], what="per-frame dB")
+    assert_db(st["fftHM"], st_ref.hm, what="waterfall ring")
+    want_rows = np.array([orc.plotcompress(r, eng.hm_width, "MAX") for r in db_ref[f1:]])
+    assert_db(rows.cpu().numpy(), want_rows, what="per-frame rows")
+    eng.close()
+
+
+def test_zero_magnitude_keeps_minus_inf(ksa):
+    """K:469: zeroSpan keeps log10(0) = -inf; it poisons Min and Avg by IEEE rules."""
+    n, full = 512, 4096
+    frames = [orc.synth_iq(full, 11), np.zeros(full), orc.synth_iq(full, 12)]
+    win = orc.window_table("hanning", n)
+    st_ref, _, _ = orc.zerospan_batch(np.array(frames), n, 0.5, win, "AVG", GAIN, 512)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN)
+    for fr in frames:
+        eng.frame(fr.astype(np.complex64))
+    st = eng.state()
+    assert np.all(np.isneginf(st_ref.min)) and np.all(np.isneginf(st["Fft.Min"]))
+    assert np.all(np.isneginf(st_ref.avg)) and np.all(np.isneginf(st["Fft.Avg"]))
+    assert_db(st["Fft.Max"], st_ref.max, what="max")
+    assert_db(st["Fft.Cur"], st_ref.cur, what="cur")
+    eng.close()
+
+
+def test_zerospan_play_spectra(ksa):
+    """zeroSpanPlay (config 1): saved linear spectra drive the accumulate + waterfall only."""
+    g = golden("zerospan_save_n512")
+    n, frames = int(g["fft_size"]), int(g["frames"])
+    eng = ksa.SpectrumEngine(n, non_overlap=0.5, window="hanning", gain=float(g["header"][2]))
+    for f in range(frames):
+        eng.frame_spectrum(g["spectra"][f])
+    st = eng.state()
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], g["play_" + k], what="play " + k)
+    # and the spectra themselves are what curscan produces for the recorded IQ
+    x = g["iq"].reshape(frames, int(g["full"]))
+    assert_lin(eng.curscan(x[2]), g["spectra"][2], what="saved spectrum")
+    eng.close()
+
+
+def test_adj_siglvls_and_flags(ksa):
+    n, full = 512, 4096
+    x = orc.synth_iq(full * 3, 21).astype(np.complex64).reshape(3, full)
+    adj = np.linspace(-3, 3, n)
+    win = orc.window_table("kaiser", n)
+    st_ref = orc.ZeroSpanState(n, 128, GAIN, adj=adj, b_min=False)
+    for fr in x:
+        st_ref.push(orc.curscan(fr, n, 0.5, win, "AVG"))
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="kaiser", gain=GAIN, xres=128)
+    eng.set_adj(adj)
+    eng.set_flags(b_max=True, b_min=False, b_avg=True)
+    for fr in x:
+        eng.frame(fr)
+    st = eng.state()
+    assert_db(st["fftHM"][:3], st_ref.hm[:3], what="adj waterfall")
+    assert_db(st["Fft.Avg"], st_ref.avg, what="avg")
+    assert np.all(st["Fft.Min"] == 0)      # never written when bDataMin is off (reference leaves None)
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ scan
+@pytest.mark.parametrize("tag", ["3band_n512", "frac_n256", "quick_n64"])
+def test_scan_vs_reference_golden(ksa, torch_cuda, tag):
+    torch = torch_cuda
+    g = golden("scan_" + tag)
+    n, full = int(g["fft_size"]), int(g["full"])
+    passes, steps = int(g["passes"]), int(g["steps"])
+    groups = int((float(g["end_freq"]) - float(g["start_freq"])) / float(g["sampling_rate"]))
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=float(g["non_overlap"]), window=str(g["window"]),
+                             gain=float(g["gain"]), min_amp=float(g["min_amp"]), xres=int(g["xres"]),
+                             max_frames=steps, scan_total_entries=groups * n,
+                             scan_non_overlap=float(g["scan_non_overlap"]))
+    x = torch.view_as_real(torch.from_numpy(g["iq"].reshape(passes, steps, full))).cuda()
+    for p in range(passes):
+        eng.scan_pass_dev(x[p], ksa.FMT_C64, steps)
+    st = eng.scan_state()
+    assert st["passes"] == passes and st["hm_index"] == int(g["hm_index"])
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], g[k], what=tag + " " + k)
+    want_hm = g["hm"]
+    assert_db(st["fftHM"][:passes], want_hm[:passes], what=tag + " hm")
+    assert np.allclose(st["fftHM"][passes:], want_hm[passes:], rtol=1e-6)   # untouched rows = minAmp4Clip
+    eng.close()
+
+
+def test_scan_dummy_band(ksa, torch_cuda):
+    """A band whose tune failed is replaced by ones(fftSize) (K:637-639)."""
+    torch = torch_cuda
+    n, full, fs = 256, 2048, 2.4e6
+    start, end = 100e6, 104.8e6
+    steps = len(orc.scan_steps(start, end, fs, 0.5))
+    x = orc.synth_iq(full * steps, 31).astype(np.complex64).reshape(steps, full)
+    win = orc.window_table("hanning", n)
+    ok = np.ones(steps, dtype=np.uint8)
+    ok[1] = 0
+    ref = orc.ScanState(n, start, end, fs, GAIN, 1e-7, 64)
+    ref.run_pass([orc.curscan(x[s], n, 0.1, win, "AVG") if ok[s] else None for s in range(steps)])
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.1, window="hanning", gain=GAIN, min_amp=1e-7,
+                             xres=64, max_frames=steps, scan_total_entries=ref.total)
+    eng.scan_pass_dev(torch.view_as_real(torch.from_numpy(x)).cuda(), ksa.FMT_C64, steps, step_ok=ok)
+    st = eng.scan_state()
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], getattr(ref, k), what="dummy " + k)
+    eng.close()
+
+
+# ------------------------------------------------------------------------- size-independent properties
+def test_full_size_batch_properties(ksa, torch_cuda):
+    """Config-2 shape at bench scale: replicated frames must give identical rows, Max == Min == Cur,
+    and scaling the input by 4 moves every dB value by 10*log10(4)."""
+    torch = torch_cuda
+    n, full, frames = 4096, 32768, 2048
+    base = orc.synth_iq(full, 99).astype(np.complex64)
+    one = torch.view_as_real(torch.from_numpy(base)).cuda()
+    dev = one.unsqueeze(0).expand(frames, full, 2).contiguous()
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, max_frames=frames)
+    cur = torch.empty((frames, n), dtype=torch.float32, device="cuda")
+    eng.frames_dev(dev, ksa.FMT_C64, frames, cur_db=cur)
+    torch.cuda.synchronize()
+    assert bool((cur == cur[0]).all())
+    st = eng.state()
+    assert np.array_equal(st["Fft.Max"], st["Fft.Min"]) and np.array_equal(st["Fft.Max"], st["Fft.Cur"])
+    assert np.max(np.abs(st["Fft.Avg"] - st["Fft.Cur"])) < 1e-4
+    want = orc.log_no_gain(orc.curscan(base, n, 0.5, orc.window_table("hanning", n)), GAIN)
+    assert_db(st["Fft.Cur"], want, what="bench-size frame")
+    eng.reset()
+    eng.frames_dev(dev * 4.0, ksa.FMT_C64, frames, cur_db=cur)
+    st4 = eng.state()
+    assert np.max(np.abs(st4["Fft.Cur"] - st["Fft.Cur"] - 10 * np.log10(4.0))) < 1e-4
+    eng.close()
