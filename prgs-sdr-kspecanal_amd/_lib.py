@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libksa.so")
+# KSA_LIB: alternative build of the same ABI (kernel-variant experiments); default = the in-tree library
+LIB_PATH = os.environ.get("KSA_LIB") or os.path.join(HERE, "libksa.so")
 
 ABI_VERSION = 1
 HM_ROWS = 128

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -170,6 +171,13 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
   p.hm_ring = with_hm ? e->d_hm : nullptr;
   p.hm_index0 = e->hm_index;
   p.hm_first = std::max(0, nframes - KSA_HM_ROWS);
+#ifdef KSA_STAMPS
+  static unsigned long long* dbg = nullptr;   // diagnostic build: 4096 blocks x 16 waves x 10 segments
+  const size_t dbg_n = 4096 * 16 * 10;
+  if (!dbg) hipMalloc(reinterpret_cast<void**>(&dbg), dbg_n * 8);
+  hipMemsetAsync(dbg, 0, dbg_n * 8, e->stream);
+  p.dbg = dbg;
+#endif
   hipEvent_t ea, eb;
   if (prof_begin(e, &ea, &eb)) return 1;
   int rc;
@@ -180,6 +188,26 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
     rc = fmt == KSA_FMT_C64 ? launch_spec_n<ksa::FMT_C64>(e, p, false) : launch_spec_n<ksa::FMT_U8>(e, p, false);
     if (rc) return rc;
   }
+#ifdef KSA_STAMPS
+  if (const char* path = getenv("KSA_STAMPS_FILE")) {
+    hipStreamSynchronize(e->stream);
+    std::vector<unsigned long long> h(dbg_n);
+    hipMemcpy(h.data(), dbg, dbg_n * 8, hipMemcpyDeviceToHost);
+    double sum[10] = {0};
+    long long waves = 0;
+    for (size_t w = 0; w < dbg_n / 10; ++w) {
+      if (!h[w * 10 + 0] && !h[w * 10 + 7]) continue;
+      ++waves;
+      for (int i = 0; i < 10; ++i) sum[i] += (double)h[w * 10 + i];
+    }
+    if (FILE* f = fopen(path, "a")) {
+      fprintf(f, "waves %lld nframes %d nwin %d :", waves, nframes, p.nwin);
+      for (int i = 0; i < 10; ++i) fprintf(f, " %.0f", waves ? sum[i] / waves : 0.0);
+      fprintf(f, "\n");
+      fclose(f);
+    }
+  }
+#endif
   return prof_end(e, ea, eb);
 }
 

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "ksa_fft.hpp"
 
 namespace ksa {
@@ -41,6 +42,7 @@ struct SpecParams {
   float* hm_ring;           // [128][hm_w] or null
   int hm_index0;            // ring row of frame 0
   int hm_first;             // first frame stored in the ring
+  unsigned long long* dbg;  // diagnostic builds only (-DKSA_STAMPS): [grid][16] cycle sums; null otherwise
 };
 
 __device__ __forceinline__ float db_of(float lin, float gain) { return 10.0f * log10f(lin) - gain; }
@@ -103,8 +105,52 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// In-kernel cycle stamps (diagnostic build only; never compiled into the shipped library).
+#ifdef KSA_STAMPS
+#define KSA_STAMP(i)                                                                        \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    unsigned long long _t;                                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    seg[i] += _t - t_last;                                                                  \
+    t_last = _t;                                                                            \
+  } while (0)
+#else
+#define KSA_STAMP(i) do {} while (0)
+#endif
+
+#ifdef KSA_ABL_NOLDS   // timing-only ablation build (no exchange): wrong results by construction
+#define KSA_SYNC() do {} while (0)
+#define KSA_LDS_ST(dst, val) do {} while (0)
+#define KSA_LDS_LD(dst, src) do {} while (0)
+#else
+#define KSA_SYNC() __syncthreads()
+#define KSA_LDS_ST(dst, val) (dst) = (val)
+#define KSA_LDS_LD(dst, src) (dst) = (src)
+#endif
+
+// Per-size launch tuning (measured on MI355X): waves per SIMD the register allocator must
+// leave room for, and whether the next window's IQ is prefetched into VGPRs.  LDS caps a CU at four
+// 4096-point transforms in flight whatever the register count, and the kernel is VALU-issue bound, so
+// for T <= 256 three spill-free waves with prefetch beat four spilling ones; 1024-thread workgroups
+// need 4 waves per SIMD by construction.
+template <int N>
+struct Tune {
+#ifdef KSA_WAVES_PER_SIMD
+  static constexpr int WPS = KSA_WAVES_PER_SIMD;
+#else
+  static constexpr int WPS = Plan<N>::T >= 512 ? 4 : 3;
+#endif
+#ifdef KSA_PREFETCH
+  static constexpr bool PF = KSA_PREFETCH;
+#else
+  static constexpr bool PF = Plan<N>::T < 512;
+#endif
+};
+
 template <int N, int FMT>
-__global__ __launch_bounds__(Plan<N>::T, 4) void spectrum_kernel(const SpecParams p) {
+__global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(const SpecParams p) {
   using P = Plan<N>;
   constexpr int L = P::L, T = P::T, S = P::S, M = P::M, R0 = P::R0, B0 = P::B0, NPAD = P::NPAD;
   constexpr int SB = FMT == FMT_C64 ? 8 : 2;  // bytes per IQ sample
@@ -112,7 +158,7 @@ __global__ __launch_bounds__(Plan<N>::T, 4) void spectrum_kernel(const SpecParam
   float2* const tw_lds = lds + S * NPAD;
 
   const int tid = threadIdx.x;
-  const int slot = tid / L;
+  const int slot = S == 1 ? 0 : tid / L;   // S == 1: constant, keeps window indices wave-uniform (scalar loads)
   const int l = tid - slot * L;
   float2* const my = lds + slot * NPAD;
 
@@ -145,57 +191,96 @@ __global__ __launch_bounds__(Plan<N>::T, 4) void spectrum_kernel(const SpecParam
   const int rounds = (p.nwin + S - 1) / S;
   const int nm1 = p.nwin - 1;
 
+  // Raw IQ of one window per thread: 16 samples l + L*q.  The loads for the NEXT window are issued
+  // right after the current one has been consumed, so their HBM/L2 latency runs under the two
+  // remaining passes (plain VMEM loads stay in flight across s_barrier).
+  typedef typename std::conditional<FMT == FMT_C64, u32x2, unsigned short>::type raw_t;
+  raw_t raw[16];
+  // Loads of window k of frame `fr`, addressed relative to the wave-uniform frame `base_fr` so that the
+  // buffer descriptor is built from scalars only (a per-lane descriptor makes hipcc wrap every load in
+  // a readfirstlane "waterfall" loop).  The descriptor spans base_fr .. base_fr + gridDim.x frames
+  // (clipped to the batch), every load is range-checked by the hardware.
+  auto issue_loads = [&](int base_fr, int fr, int k) {
+    const char* fbase = reinterpret_cast<const char*>(p.iq) + (long long)base_fr * p.frame_stride * SB;
+    int span = p.nframes - 1 - base_fr;
+    if (span > (int)gridDim.x) span = gridDim.x;
+    const long long bytes = ((long long)span * p.frame_stride + p.frame_len) * SB;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fbase), 0, (int)bytes, 0x00020000);
+    const int voff = ((fr - base_fr) * (int)p.frame_stride + p.starts[k] + l) * SB;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+#ifdef KSA_ABL_NOLOAD   // timing-only ablation build: wrong results by construction
+      if constexpr (FMT == FMT_C64) { raw[q].x = voff + q; raw[q].y = voff * q; }
+      else raw[q] = voff + q;
+#else
+      if constexpr (FMT == FMT_C64) raw[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, L * q * SB, 0);
+      else raw[q] = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, L * q * SB, 0);
+#endif
+    }
+  };
+  constexpr bool PF = Tune<N>::PF;
+  if (PF && (int)blockIdx.x < p.nframes && slot < p.nwin) issue_loads(blockIdx.x, blockIdx.x, slot);
+
+#ifdef KSA_STAMPS
+  unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
   for (int frame = blockIdx.x; frame < p.nframes; frame += gridDim.x) {
     float acc[16];
     const float init = p.cumu == CUMU_MIN ? __builtin_inff() : 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = init;
-    // one buffer descriptor per frame: wave-uniform base, hardware range check on every load
-    const char* fbase = reinterpret_cast<const char*>(p.iq) + (long long)frame * p.frame_stride * SB;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fbase), 0, p.frame_len * SB, 0x00020000);
 
     for (int rd = 0; rd < rounds; ++rd) {
-      const int k = rd * S + slot;
+      const int k = S == 1 ? rd : rd * S + slot;   // wave-uniform when one transform fills the workgroup
       const bool active = S == 1 || k < p.nwin;
       float2 v[16];
+      if (!PF && active) issue_loads(frame, frame, k);
       if (active) {
-        const int voff = (p.starts[k] + l) * SB;
-        if constexpr (FMT == FMT_C64) {
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, L * q * SB, 0);
+        for (int q = 0; q < 16; ++q) {
+          if constexpr (FMT == FMT_C64) {
             // (scalar copies first: __builtin_bit_cast on a vector element reads element 0 twice)
-            const unsigned xr = x.x, xi = x.y;
+            const unsigned xr = raw[q].x, xi = raw[q].y;
             v[(q % B0) * R0 + (q / B0)] = make_float2(__uint_as_float(xr) * win[q], __uint_as_float(xi) * win[q]);
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const unsigned short x = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, L * q * SB, 0);
+          } else {
+            const unsigned short x = raw[q];
             v[(q % B0) * R0 + (q / B0)] = make_float2(fmaf((float)(x & 0xff), win[q], wof[q]),
                                                       fmaf((float)(x >> 8), win[q], wof[q]));
           }
         }
+      }
+      if (PF) {
+        int nk = k + S, nf = frame;
+        if (nk >= p.nwin) { nk = slot; nf = frame + gridDim.x; }
+        if (nf < p.nframes && nk < p.nwin) issue_loads(frame, nf, nk);
+      }
+      KSA_STAMP(0);
+      if (active) {
         dft_first<R0>(v);
       }
+      KSA_STAMP(1);
       if constexpr (M >= 2) {
-        __syncthreads();  // previous round's / frame's LDS reads are done
+        KSA_SYNC();  // previous round's / frame's LDS reads are done
+        KSA_STAMP(2);
         if (active) {
 #pragma unroll
           for (int b = 0; b < B0; ++b) {
             const int i = l + b * L;  // butterfly index, p = 1
 #pragma unroll
-            for (int t = 0; t < R0; ++t) my[padi(i * R0 + perm<R0>(t))] = v[b * R0 + t];
+            for (int t = 0; t < R0; ++t) KSA_LDS_ST(my[padi(i * R0 + perm<R0>(t))], v[b * R0 + t]);
           }
         }
-        __syncthreads();
+        KSA_SYNC();
+        KSA_STAMP(3);
         int pp = R0;       // product of the radices already applied
         int tw_off = 0;
 #pragma unroll
         for (int s = 1; s < M; ++s) {
           if (active) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = my[padi(l + L * t)];
+            for (int t = 0; t < 16; ++t) KSA_LDS_LD(v[t], my[padi(l + L * t)]);
             if (s < M - 1) {
               const float2* tw = tw_lds + tw_off + (l & (pp - 1));
               dft16_tw(v, tw[0], tw[pp], tw[2 * pp], tw[3 * pp], tw[7 * pp], tw[11 * pp]);
@@ -203,15 +288,17 @@ __global__ __launch_bounds__(Plan<N>::T, 4) void spectrum_kernel(const SpecParam
               dft16_tw(v, w1, w2, w3, w4, w8, w12);
             }
           }
+          KSA_STAMP(s < M - 1 ? 4 : 6);
           if (s < M - 1) {
-            __syncthreads();
+            KSA_SYNC();
             if (active) {
               const int kk = l & (pp - 1);
               const int j = (l - kk) * 16 + kk;
 #pragma unroll
-              for (int t = 0; t < 16; ++t) my[padi(j + perm<16>(t) * pp)] = v[t];
+              for (int t = 0; t < 16; ++t) KSA_LDS_ST(my[padi(j + perm<16>(t) * pp)], v[t]);
             }
-            __syncthreads();
+            KSA_SYNC();
+            KSA_STAMP(5);
             tw_off += 15 * pp;
             pp *= 16;
           }
@@ -234,6 +321,7 @@ __global__ __launch_bounds__(Plan<N>::T, 4) void spectrum_kernel(const SpecParam
           for (int i = 0; i < 16; ++i) acc[i] = fminf(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
         }
       }
+      KSA_STAMP(7);
     }
 
     // ---- combine the slots, scale, fftshift, dB, waterfall row ------------------------------
@@ -246,7 +334,13 @@ __global__ __launch_bounds__(Plan<N>::T, 4) void spectrum_kernel(const SpecParam
     for (int i = 0; i < 16; ++i) red[slot * N + l + L * perm<16>(i)] = acc[i];
     __syncthreads();
     finish_frame<N, T, S>(p, red, frame, tid);
+    KSA_STAMP(8);
   }
+#ifdef KSA_STAMPS
+  if (p.dbg && (tid & 63) == 0) {
+    for (int i = 0; i < 10; ++i) p.dbg[((long long)blockIdx.x * (T / 64) + tid / 64) * 10 + i] = seg[i];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
