@@ -93,6 +93,57 @@ def test_curscan_large_n_golden(ksa, tag):
         eng.close()
 
 
+@pytest.mark.parametrize("tag", ["n32768_q05", "n65536_q025"])
+def test_curscan_four_step_golden(ksa, tag):
+    """N > 16384 runs the two-kernel four-step path; config 5 geometry (65536, 75 % overlap, 29 windows)."""
+    g = golden("curscan_" + tag)
+    n, q, full = int(g["fft_size"]), float(g["non_overlap"]), int(g["full"])
+    x = orc.synth_iq(full, int(g["seed"])).astype(np.complex64)
+    for mode, key, dec in (("AVG", "avg_at_idx", "avg_decim"), ("MAX", "max_at_idx", "max_decim")):
+        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=str(g["window"]), cumu_mode=mode)
+        assert eng.kernel_info()["path"] == 1
+        y = eng.curscan(x)
+        peak = float(g["peak"])
+        assert np.max(np.abs(y[g["idx"]] - g[key])) / peak <= 1e-5
+        red = y.reshape(256, -1).sum(axis=1) if mode == "AVG" else y.reshape(256, -1).max(axis=1)
+        assert np.max(np.abs(red - g[dec])) / np.max(g[dec]) <= 1e-5
+        eng.close()
+
+
+@pytest.mark.parametrize("n,q,fmt", [(32768, 0.5, "c64"), (65536, 0.25, "u8"), (131072, 0.5, "c64"), (1048576, 0.5, "c64")])
+def test_four_step_full_spectrum_vs_oracle(ksa, n, q, fmt):
+    full = 2 * n
+    x = orc.synth_iq(full, 4000 + (n >> 10))
+    if fmt == "u8":
+        raw = orc.quantize_u8(x * 0.8)
+        xin, arg = orc.unpack_u8(raw), raw
+    else:
+        xin = arg = x.astype(np.complex64)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning", cumu_mode="AVG")
+    want = orc.curscan(xin, n, q, orc.window_table("hanning", n), "AVG")
+    assert_lin(eng.curscan(arg), want, what="four-step N=%d" % n)
+    eng.close()
+
+
+def test_four_step_zerospan_state(ksa, torch_cuda):
+    """Config 5 shape end to end: frames_dev on the four-step path incl. waterfall rows (g = 128 bins per cell)."""
+    torch = torch_cuda
+    n, q, full, frames = 65536, 0.25, 524288, 3
+    x = orc.synth_iq(full * frames, 555).astype(np.complex64).reshape(frames, full)
+    st_ref, db_ref, _ = orc.zerospan_batch(x, n, q, orc.window_table("hanning", n), "AVG", GAIN, 512)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning", gain=GAIN, max_frames=frames)
+    assert eng.num_windows == 29
+    dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+    rows = torch.empty((frames, 512), dtype=torch.float32, device="cuda")
+    eng.frames_dev(dev, ksa.FMT_C64, frames, hm_rows=rows)
+    st = eng.state()
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], getattr(st_ref, k), what="four-step " + k)
+    assert_db(st["fftHM"][:frames], st_ref.hm[:frames], what="four-step waterfall")
+    assert_db(rows.cpu().numpy(), st_ref.hm[:frames], what="four-step rows")
+    eng.close()
+
+
 def test_on_bin_tone_known_answer(ksa):
     g = golden("tone_n4096")
     for w in WINDOWS:
