@@ -71,6 +71,7 @@ struct ksa_engine {
   int max_chunks = 1;
   // launch config of the spectrum kernel
   int path = 0, threads = 0, lds_bytes = 0, vgprs = 0, blocks_per_cu = 1;
+  int reuse_m = 0;              // new samples per thread per window when hops are a fixed multiple of N/16
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -82,10 +83,10 @@ namespace {
 
 using ksa::SpecParams;
 
-template <int N, int FMT>
+template <int N, int FMT, int RM>
 int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
   using P = ksa::Plan<N>;
-  auto kfn = ksa::spectrum_kernel<N, FMT>;
+  auto kfn = ksa::spectrum_kernel<N, FMT, RM>;
   if (configure_only) {
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES));
     hipFuncAttributes attr;
@@ -106,20 +107,31 @@ int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
   return 0;
 }
 
+// sample-reuse variants exist where one transform fills the workgroup (N >= 1024)
+template <int N, int FMT>
+int launch_spec_rm(ksa_engine* e, const SpecParams& p, bool cfg_only, int rm) {
+  if constexpr (ksa::Plan<N>::S == 1) {
+    if (rm == 8) return launch_spec_t<N, FMT, 8>(e, p, cfg_only);
+    if (rm == 4) return launch_spec_t<N, FMT, 4>(e, p, cfg_only);
+  }
+  return launch_spec_t<N, FMT, 0>(e, p, cfg_only);
+}
+
 template <int FMT>
 int launch_spec_n(ksa_engine* e, const SpecParams& p, bool cfg_only) {
+  const int rm = p.nwin > 1 ? e->reuse_m : 0;   // RAW mode transforms a single window: nothing to reuse
   switch (e->cfg.fft_size) {
-    case 16: return launch_spec_t<16, FMT>(e, p, cfg_only);
-    case 32: return launch_spec_t<32, FMT>(e, p, cfg_only);
-    case 64: return launch_spec_t<64, FMT>(e, p, cfg_only);
-    case 128: return launch_spec_t<128, FMT>(e, p, cfg_only);
-    case 256: return launch_spec_t<256, FMT>(e, p, cfg_only);
-    case 512: return launch_spec_t<512, FMT>(e, p, cfg_only);
-    case 1024: return launch_spec_t<1024, FMT>(e, p, cfg_only);
-    case 2048: return launch_spec_t<2048, FMT>(e, p, cfg_only);
-    case 4096: return launch_spec_t<4096, FMT>(e, p, cfg_only);
-    case 8192: return launch_spec_t<8192, FMT>(e, p, cfg_only);
-    case 16384: return launch_spec_t<16384, FMT>(e, p, cfg_only);
+    case 16: return launch_spec_rm<16, FMT>(e, p, cfg_only, rm);
+    case 32: return launch_spec_rm<32, FMT>(e, p, cfg_only, rm);
+    case 64: return launch_spec_rm<64, FMT>(e, p, cfg_only, rm);
+    case 128: return launch_spec_rm<128, FMT>(e, p, cfg_only, rm);
+    case 256: return launch_spec_rm<256, FMT>(e, p, cfg_only, rm);
+    case 512: return launch_spec_rm<512, FMT>(e, p, cfg_only, rm);
+    case 1024: return launch_spec_rm<1024, FMT>(e, p, cfg_only, rm);
+    case 2048: return launch_spec_rm<2048, FMT>(e, p, cfg_only, rm);
+    case 4096: return launch_spec_rm<4096, FMT>(e, p, cfg_only, rm);
+    case 8192: return launch_spec_rm<8192, FMT>(e, p, cfg_only, rm);
+    case 16384: return launch_spec_rm<16384, FMT>(e, p, cfg_only, rm);
     default: return fail("fft_size %d has no single-workgroup plan", e->cfg.fft_size);
   }
 }
@@ -346,7 +358,16 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     }
     if ((rc = upload(&e->d_tw_mid, mid.data(), mid.size()))) return bail(rc);
     if ((rc = upload(&e->d_tw_last, last.data(), last.size()))) return bail(rc);
+    // constant hop that is 4/16 or 8/16 of the transform: raw samples are carried over in registers
+    if (cfg->num_windows > 1 && n >= 1024) {
+      const int hop = cfg->window_starts[1] - cfg->window_starts[0];
+      bool same = true;
+      for (int i = 2; i < cfg->num_windows; ++i) same &= cfg->window_starts[i] - cfg->window_starts[i - 1] == hop;
+      if (same && (hop == n / 2 || hop == n / 4)) e->reuse_m = hop / (n / 16);
+    }
+    if (getenv("KSA_NO_REUSE")) e->reuse_m = 0;   // A/B switch for measurements
     SpecParams dummy{};
+    dummy.nwin = cfg->num_windows;
     if ((rc = launch_spec_n<ksa::FMT_C64>(e, dummy, true))) return bail(rc);
     if ((rc = launch_spec_n<ksa::FMT_U8>(e, dummy, true))) return bail(rc);
   } else {

@@ -49,43 +49,65 @@ __device__ __forceinline__ float db_of(float lin, float gain) { return 10.0f * l
 
 // Output stage of one frame (rows A7 tail, A8, A9, A12): slot combine, 2*winAdj/N scale, fftshift,
 // LogNoGain / Clip2MinAmp, store, waterfall cell max.  red = [S][N] floats in LDS.
+#ifndef KSA_FIN_U
+#define KSA_FIN_U 1
+#endif
+#ifdef KSA_FIN_NOINLINE
+#define KSA_FIN_ATTR __noinline__
+#else
+#define KSA_FIN_ATTR __forceinline__
+#endif
 template <int N, int T, int S>
-__device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, int frame, int tid) {
+__device__ KSA_FIN_ATTR void finish_frame(const SpecParams& p, float* red, int frame, int tid) {
   const int g = p.hm_w > 0 ? N / p.hm_w : 0;  // bins per waterfall cell
   const bool hm_shfl = g > 0 && g <= 64 && g <= T;
   float* const orow = p.out + (long long)frame * N;
+  float* const hm_row = p.hm_rows ? p.hm_rows + (long long)frame * p.hm_w : nullptr;
+  float* const hm_ring = (p.hm_ring && frame >= p.hm_first)
+                             ? p.hm_ring + ((p.hm_index0 + frame) % HM_ROWS) * p.hm_w : nullptr;
+  constexpr int U = KSA_FIN_U;  // independent bins per iteration
 #pragma unroll 1
-  for (int bin = tid; bin < N; bin += T) {
-    float r = red[bin];
-    if constexpr (S > 1) {
+  for (int base = tid; base < N; base += U * T) {
+    float o[U];
+    int sh[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int bin = base + u * T;
+      const bool ok = bin < N;
+      float r = ok ? red[bin] : 1.0f;
+      if constexpr (S > 1) {
 #pragma unroll 1
-      for (int s2 = 1; s2 < S; ++s2) {
-        const float o = red[s2 * N + bin];
-        r = p.cumu == CUMU_AVG ? r + o : p.cumu == CUMU_MAX ? fmaxf(r, o) : fminf(r, o);
-      }
-    }
-    float lin = p.cumu == CUMU_AVG ? r : __builtin_amdgcn_sqrtf(r);
-    lin *= p.scale;
-    const int sh = (bin + N / 2) & (N - 1);
-    float o = lin;
-    if (p.out_mode != OUT_LINEAR) {
-      if (p.out_mode == OUT_DB_CLIP) lin = fmaxf(lin, p.min_amp);
-      o = db_of(lin, p.gain);
-    }
-    orow[sh] = o;
-    if (g > 0) {
-      float hv = p.adj ? o - p.adj[sh] : o;
-      if (hm_shfl) {
-        // g consecutive lanes hold g consecutive bins of one cell
-        for (int m = 1; m < g; m <<= 1) hv = fmaxf(hv, __shfl_xor(hv, m));
-        if ((tid & (g - 1)) == 0) {
-          const int cell = sh / g;
-          if (p.hm_rows) p.hm_rows[(long long)frame * p.hm_w + cell] = hv;
-          if (p.hm_ring && frame >= p.hm_first)
-            p.hm_ring[((p.hm_index0 + frame) % HM_ROWS) * p.hm_w + cell] = hv;
+        for (int s2 = 1; s2 < S; ++s2) {
+          const float x = ok ? red[s2 * N + bin] : 1.0f;
+          r = p.cumu == CUMU_AVG ? r + x : p.cumu == CUMU_MAX ? fmaxf(r, x) : fminf(r, x);
         }
-      } else {
-        red[S * N + sh] = hv;  // second float plane of the data region
+      }
+      float lin = p.cumu == CUMU_AVG ? r : __builtin_amdgcn_sqrtf(r);
+      lin *= p.scale;
+      sh[u] = (bin + N / 2) & (N - 1);
+      o[u] = lin;
+      if (p.out_mode != OUT_LINEAR) {
+        if (p.out_mode == OUT_DB_CLIP) lin = fmaxf(lin, p.min_amp);
+        o[u] = db_of(lin, p.gain);
+      }
+      if (ok) orow[sh[u]] = o[u];
+    }
+    if (g > 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = base + u * T < N;
+        float hv = p.adj ? o[u] - p.adj[sh[u]] : o[u];
+        if (hm_shfl) {
+          // g consecutive lanes hold g consecutive bins of one cell
+          for (int m = 1; m < g; m <<= 1) hv = fmaxf(hv, __shfl_xor(hv, m));
+          if (ok && (tid & (g - 1)) == 0) {
+            const int cell = sh[u] / g;
+            if (hm_row) hm_row[cell] = hv;
+            if (hm_ring) hm_ring[cell] = hv;
+          }
+        } else if (ok) {
+          red[S * N + sh[u]] = hv;  // second float plane of the data region
+        }
       }
     }
   }
@@ -96,9 +118,8 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
     for (int cell = tid; cell < p.hm_w; cell += T) {
       float hv = hmbuf[cell * g];
       for (int i = 1; i < g; ++i) hv = fmaxf(hv, hmbuf[cell * g + i]);
-      if (p.hm_rows) p.hm_rows[(long long)frame * p.hm_w + cell] = hv;
-      if (p.hm_ring && frame >= p.hm_first)
-        p.hm_ring[((p.hm_index0 + frame) % HM_ROWS) * p.hm_w + cell] = hv;
+      if (hm_row) hm_row[cell] = hv;
+      if (hm_ring) hm_ring[cell] = hv;
     }
   }
 }
@@ -142,15 +163,23 @@ struct Tune {
 #else
   static constexpr int WPS = Plan<N>::T >= 512 ? 4 : 3;
 #endif
+  // prefetch only on the general path: with sample reuse the carried half plus a prefetched half spill
+  static constexpr bool pf(int rm) {
 #ifdef KSA_PREFETCH
-  static constexpr bool PF = KSA_PREFETCH;
+    return KSA_PREFETCH;
 #else
-  static constexpr bool PF = Plan<N>::T < 512;
+    return Plan<N>::T < 512 && rm == 0;
 #endif
+  }
 };
 
-template <int N, int FMT>
+// RM > 0: consecutive windows are exactly RM*L samples apart (L = N/16 threads), so thread l's samples
+// l + L*q of window k+1 are its samples q+RM of window k: the raw values stay in VGPRs and only RM new
+// samples per thread are loaded per window (50 % overlap: RM = 8, 75 %: RM = 4).  Each IQ sample is then
+// read from HBM exactly once.  RM = 0 is the general path (fractional hops, K:386).
+template <int N, int FMT, int RM>
 __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(const SpecParams p) {
+  static_assert(RM == 0 || Plan<N>::S == 1, "sample reuse needs one transform per workgroup");
   using P = Plan<N>;
   constexpr int L = P::L, T = P::T, S = P::S, M = P::M, R0 = P::R0, B0 = P::B0, NPAD = P::NPAD;
   constexpr int SB = FMT == FMT_C64 ? 8 : 2;  // bytes per IQ sample
@@ -200,7 +229,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   // buffer descriptor is built from scalars only (a per-lane descriptor makes hipcc wrap every load in
   // a readfirstlane "waterfall" loop).  The descriptor spans base_fr .. base_fr + gridDim.x frames
   // (clipped to the batch), every load is range-checked by the hardware.
-  auto issue_loads = [&](int base_fr, int fr, int k) {
+  auto issue_loads = [&](int base_fr, int fr, int k, int q0) {
     const char* fbase = reinterpret_cast<const char*>(p.iq) + (long long)base_fr * p.frame_stride * SB;
     int span = p.nframes - 1 - base_fr;
     if (span > (int)gridDim.x) span = gridDim.x;
@@ -209,6 +238,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
     const int voff = ((fr - base_fr) * (int)p.frame_stride + p.starts[k] + l) * SB;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
+      if (q < q0) continue;
 #ifdef KSA_ABL_NOLOAD   // timing-only ablation build: wrong results by construction
       if constexpr (FMT == FMT_C64) { raw[q].x = voff + q; raw[q].y = voff * q; }
       else raw[q] = voff + q;
@@ -218,8 +248,12 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
 #endif
     }
   };
-  constexpr bool PF = Tune<N>::PF;
-  if (PF && (int)blockIdx.x < p.nframes && slot < p.nwin) issue_loads(blockIdx.x, blockIdx.x, slot);
+  auto shift_raw = [&]() {
+#pragma unroll
+    for (int q = 0; q + RM < 16; ++q) raw[q] = raw[q + RM];
+  };
+  constexpr bool PF = Tune<N>::pf(RM);
+  if (PF && (int)blockIdx.x < p.nframes && slot < p.nwin) issue_loads(blockIdx.x, blockIdx.x, slot, 0);
 
 #ifdef KSA_STAMPS
   unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -236,7 +270,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       const int k = S == 1 ? rd : rd * S + slot;   // wave-uniform when one transform fills the workgroup
       const bool active = S == 1 || k < p.nwin;
       float2 v[16];
-      if (!PF && active) issue_loads(frame, frame, k);
+      if (!PF && active) issue_loads(frame, frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
       if (active) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -254,7 +288,16 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       if (PF) {
         int nk = k + S, nf = frame;
         if (nk >= p.nwin) { nk = slot; nf = frame + gridDim.x; }
-        if (nf < p.nframes && nk < p.nwin) issue_loads(frame, nf, nk);
+        if (nf < p.nframes && nk < p.nwin) {
+          if (RM > 0 && nf == frame) {
+            shift_raw();
+            issue_loads(frame, nf, nk, 16 - RM);
+          } else {
+            issue_loads(frame, nf, nk, 0);
+          }
+        }
+      } else if (RM > 0) {
+        shift_raw();   // the next round of this frame loads only its RM new samples
       }
       KSA_STAMP(0);
       if (active) {
