@@ -257,6 +257,32 @@ def main():
              avg_decim=y.reshape(256, -1).sum(axis=1), max_decim=ymax.reshape(256, -1).max(axis=1),
              peak=np.max(y))
 
+    # ---- CLI grammar: what handle_args leaves in gD for a set of command lines (K:778-949) ----------
+    import json
+    cli = {}
+    cases_cli = {
+        "default": [],
+        "zerospan": ["zeroSpan", "centerFreq", "91.1e6", "fftSize", "4096", "window", "hanning", "curScanNonOverlap", "0.5"],
+        "fmscan": ["FMSCAN", "gain", "7.1", "window", "kaiser"],
+        "quickfullscan": ["quickFullScan"],
+        "scan_uneven": ["scan", "startFreq", "400e6", "endFreq", "500e6", "fftSize", "2048", "samplingRate", "2e6"],
+        "xres_fix": ["zeroSpan", "fftSize", "1024", "xRes", "300"],
+        "xres_big": ["zeroSpan", "fftSize", "256", "xRes", "512"],
+        "big_fft": ["zeroSpan", "fftSize", str(2 ** 19), "curScanCumuMode", "max", "pltCompress", "max"],
+        "flags": ["ZEROSPAN", "bDataMin", "false", "bDataMax", "TRUE", "bGrid", "False", "minAmp4Clip", "1e-9",
+                  "scanRangeNonOverlap", "0.25", "pltHighsNumMarkers", "3", "pltHighsDelta4Marking", "0.1"],
+    }
+    keys = ["prgMode", "samplingRate", "gain", "centerFreq", "fftSize", "curScanNonOverlap", "curScanCumuMode",
+            "window", "minAmp4Clip", "scanRangeNonOverlap", "prgLoopCnt", "xRes", "pltCompress", "pltCompressHM",
+            "pltHighsNumMarkers", "pltHighsDelta4Marking", "bDataMin", "bDataMax", "bDataAvg", "bDataCur", "bGrid",
+            "bUsePSD", "bScanRangeBaseDataIsRaw", "startFreq", "endFreq", "fullSize", "zeroSpanSaveFile"]
+    for name, argv in cases_cli.items():
+        g = run_reference(argv + ["prgLoopCnt", 0], np.zeros(1, dtype=np.complex64))["gD"]
+        cli[name] = {"argv": argv, "d": {k: (float(g[k]) if isinstance(g[k], (float, np.floating)) else g[k]) for k in keys}}
+    with open(os.path.join(HERE, "cli_args.json"), "w") as f:
+        json.dump(cli, f, indent=1, sort_keys=True)
+    print("wrote cli_args.json")
+
     # ---- pieces: data_cumu / _data_plotcompress / data_proc direct -----------------
     rng = np.random.default_rng(SEED0 + 500)
     a = rng.standard_normal(64); b = rng.standard_normal(64)

@@ -1,0 +1,122 @@
+"""The kspecanal-compatible front end (prgs-sdr-kspecanal_amd/kspecanal.py) end to end on the GPU: the dict `d`
+it leaves behind -- the reference's plotting hand-off -- against the oracle fed with the very blocks the
+(recording) source delivered."""
+import pickle
+
+import numpy as np
+import pytest
+
+import ksa_oracle as orc
+from conftest import load_pkg
+from test_gpu_parity import assert_db, assert_lin
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def K(monkeypatch):
+    load_pkg()
+    mod = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.kspecanal")
+    src = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.sources")
+
+    class Recording(src.SyntheticSdr):
+        log = []
+
+        def read_samples(self, n):
+            x = super().read_samples(n)
+            type(self).log.append((float(self.center_freq), x.astype(np.complex64)))
+            return x
+
+        def read_bytes(self, nbytes):
+            b = src.SyntheticSdr.read_bytes(self, nbytes)
+            type(self).log[-1] = (float(self.center_freq), b)     # replace the complex record by the bytes
+            return b
+
+    Recording.log = []
+    monkeypatch.setattr(mod, "open_source", lambda d: Recording(seed=99, noise=0.02))
+    mod.Recording = Recording
+    yield mod
+    mod.sdr_curscan = mod._gpu_curscan
+
+
+def _blocks(K, full):
+    """Capture blocks in delivery order (the 16Ki settle reads of sdr_setup are dropped, K:301)."""
+    out, cur = [], []
+    for fc, x in K.Recording.log:
+        if len(x) == 16 * 1024 and not cur and full != 16 * 1024:
+            continue
+        cur.append(x)
+        if sum(len(c) for c in cur) >= full * (2 if x.dtype == np.uint8 else 1):
+            out.append((fc, np.concatenate(cur)))
+            cur = []
+    return out
+
+
+def test_zero_span_main(K):
+    d = K.main(["zeroSpan", "fftSize", "1024", "window", "hanning", "curScanNonOverlap", "0.5", "prgLoopCnt", "6",
+                "centerFreq", "100.3e6", "xRes", "256", "bPltLevels", "false", "bPltHeatMap", "false", "source", "synth"])
+    blocks = [b for _, b in _blocks(K, d["fullSize"])]
+    assert len(blocks) == 6
+    st, _, _ = orc.zerospan_batch(np.array(blocks), 1024, 0.5, orc.window_table("hanning", 1024), "AVG", d["gain"], 256)
+    for k in ("Cur", "Max", "Min", "Avg"):
+        assert_db(d["Fft." + k], getattr(st, k.lower()), what="main " + k)
+    assert_db(d["fftHM"][:6], st.hm[:6], what="main waterfall")
+    assert d["fftHMIndex"] == 6
+    want_f = np.fft.fftshift(np.fft.fftfreq(1024, 1 / 2.4e6) + 100.3e6)
+    assert np.array_equal(d["freqs"], want_f)                      # K:444-445
+    # strongest marker is the 100 MHz / 101 MHz tone of the synthetic source
+    assert abs(d["Highs"][0][0] / 1e6 - round(d["Highs"][0][0] / 1e6)) < 0.01
+
+
+def test_zero_span_uint8_source(K):
+    d = K.main(["zeroSpan", "fftSize", "512", "window", "kaiser", "prgLoopCnt", "3", "iqFormat", "u8",
+                "bPltLevels", "false", "bPltHeatMap", "false", "source", "synth"])
+    blocks = [orc.unpack_u8(b) for _, b in _blocks(K, d["fullSize"])]
+    assert len(blocks) == 3
+    st, _, _ = orc.zerospan_batch(np.array(blocks), 512, 0.1, orc.window_table("kaiser", 512), "AVG", d["gain"], 512)
+    for k in ("Cur", "Max", "Min", "Avg"):
+        assert_db(d["Fft." + k], getattr(st, k.lower()), what="u8 " + k)
+
+
+def test_zero_span_save_then_play(K, tmp_path):
+    path = str(tmp_path / "zs.save")
+    d = K.main(["zeroSpanSave", "fftSize", "512", "window", "hanning", "curScanNonOverlap", "0.5", "prgLoopCnt", "4",
+                "gain", "7.7", "zeroSpanSaveFile", path, "bPltLevels", "false", "bPltHeatMap", "false", "source", "synth"])
+    blocks = [b for _, b in _blocks(K, d["fullSize"])]
+    with open(path, "rb") as f:                                    # the stream is the reference's format (K:511-525)
+        hdr = [pickle.load(f) for _ in range(3)]
+        recs = []
+        for _ in range(4):
+            t, a = pickle.load(f), pickle.load(f)
+            assert isinstance(t, float) and a.dtype == np.float64 and a.shape == (512,)
+            recs.append(a)
+    assert hdr == [d["centerFreq"], d["samplingRate"], 7.7]
+    win = orc.window_table("hanning", 512)
+    for a, b in zip(recs, blocks):
+        assert_lin(a, orc.curscan(b, 512, 0.5, win, "AVG"), what="saved spectrum")
+    d2 = K.main(["zeroSpanPlay", "fftSize", "512", "zeroSpanPlayFile", path, "prgLoopCnt", "10",
+                 "bPltLevels", "false", "bPltHeatMap", "false"])
+    assert d2["gain"] == 7.7 and d2["cmd.stop"] is True            # header overrides, EOF stops the loop
+    st = orc.ZeroSpanState(512, 512, 7.7)
+    for a in recs:
+        st.push(np.copy(a))
+    for k in ("Cur", "Max", "Min", "Avg"):
+        assert_db(d2["Fft." + k], getattr(st, k.lower()), what="play " + k)
+
+
+def test_scan_main(K):
+    d = K.main(["scan", "startFreq", "99e6", "endFreq", "106e6", "fftSize", "512", "window", "hanning", "prgLoopCnt", "2",
+                "xRes", "128", "bPltLevels", "false", "bPltHeatMap", "false", "source", "synth"])
+    assert d["endFreq"] == 99e6 + 3 * 2.4e6                        # K:701-709
+    groups, total, centers = K.scan_geometry(d)
+    blocks = _blocks(K, d["fullSize"])
+    assert len(blocks) == 2 * len(centers)
+    assert [fc for fc, _ in blocks[:len(centers)]] == centers      # retune order K:689
+    ref = orc.ScanState(512, d["startFreq"], d["endFreq"], d["samplingRate"], d["gain"], d["minAmp4Clip"], 128)
+    win = orc.window_table("hanning", 512)
+    for p in range(2):
+        ref.run_pass([orc.curscan(b, 512, 0.1, win, "AVG") for _, b in blocks[p * len(centers):(p + 1) * len(centers)]])
+    for k in ("Cur", "Max", "Min", "Avg"):
+        assert_db(d["Fft." + k], getattr(ref, k.lower()), what="scan " + k)
+    assert_db(d["fftHM"][:2], ref.hm[:2], what="scan waterfall")
+    assert np.array_equal(d["freqsAll"], np.fft.fftshift(np.fft.fftfreq(total, 1 / (groups * 2.4e6)) + 99e6 + groups * 1.2e6))
