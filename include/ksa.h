@@ -11,6 +11,7 @@
  * the engine's device.  One engine = one GPU; no concurrent calls on one engine (the reference is
  * single threaded: K:505, K:1118-1123).  All device work is enqueued on the engine's stream
  * (ksa_set_stream) and host-pointer entry points synchronise that stream before returning.
+ * Device output buffers (spectra, waterfall rows) must be 16-byte aligned; IQ buffers sample aligned.
  */
 #ifndef KSA_H
 #define KSA_H

@@ -36,16 +36,16 @@ __device__ __forceinline__ float2 mul_w16(float2 v) {
   else { static_assert(M < 0, "unsupported W16 exponent"); return v; }
 }
 
-template <int BASE, int STRIDE>
-__device__ __forceinline__ void dft2(float2 (&v)[16]) {
+template <int BASE, int STRIDE, int SZ>
+__device__ __forceinline__ void dft2(float2 (&v)[SZ]) {
   float2 a = v[BASE], b = v[BASE + STRIDE];
   v[BASE] = cadd(a, b);
   v[BASE + STRIDE] = csub(a, b);
 }
 
 // natural-order in-place radix-4 on v[BASE + STRIDE*{0,1,2,3}]
-template <int BASE, int STRIDE>
-__device__ __forceinline__ void dft4(float2 (&v)[16]) {
+template <int BASE, int STRIDE, int SZ>
+__device__ __forceinline__ void dft4(float2 (&v)[SZ]) {
   float2 a0 = v[BASE], a1 = v[BASE + STRIDE], a2 = v[BASE + 2 * STRIDE], a3 = v[BASE + 3 * STRIDE];
   float2 s0 = cadd(a0, a2), d0 = csub(a0, a2);
   float2 s1 = cadd(a1, a3), d1 = csub(a1, a3);
@@ -56,8 +56,8 @@ __device__ __forceinline__ void dft4(float2 (&v)[16]) {
 }
 
 // radix-8 on v[BASE..BASE+7]; position BASE+P ends up holding X[perm8(P)]
-template <int BASE>
-__device__ __forceinline__ void dft8(float2 (&v)[16]) {
+template <int BASE, int SZ>
+__device__ __forceinline__ void dft8(float2 (&v)[SZ]) {
   dft4<BASE + 0, 2>(v);
   dft4<BASE + 1, 2>(v);
   v[BASE + 3] = mul_w16<2>(v[BASE + 3]);  // W8^1
