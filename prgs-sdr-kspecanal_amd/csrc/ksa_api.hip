@@ -37,6 +37,16 @@ int fail(const char* fmt, ...) {
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+// host mirror of ksa::Tune<N>::FUSED (the twiddle table layout depends on it)
+bool tune_fused(int n) {
+#ifdef KSA_FUSED
+  (void)n;
+  return KSA_FUSED;
+#else
+  return n <= 4096;
+#endif
+}
+
 }  // namespace
 
 struct ksa_engine {
@@ -88,21 +98,21 @@ int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
   using P = ksa::Plan<N>;
   auto kfn = ksa::spectrum_kernel<N, FMT, RM>;
   if (configure_only) {
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES));
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, ksa::Tune<N>::LDS_BYTES));
     hipFuncAttributes attr;
     HIP_OK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kfn)));
     int occ = 0;
-    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, P::T, P::LDS_BYTES));
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, P::T, ksa::Tune<N>::LDS_BYTES));
     if (FMT == ksa::FMT_C64) {
       e->threads = P::T;
-      e->lds_bytes = P::LDS_BYTES;
+      e->lds_bytes = ksa::Tune<N>::LDS_BYTES;
       e->vgprs = attr.numRegs;
       e->blocks_per_cu = std::max(1, occ);
     }
     return 0;
   }
   const int grid = std::max(1, std::min(p.nframes, e->num_cu * e->blocks_per_cu));
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), P::LDS_BYTES, e->stream, p);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), ksa::Tune<N>::LDS_BYTES, e->stream, p);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -236,12 +246,13 @@ int run_accumulate(ksa_engine* e, const float* db, int nframes, long long first_
   a.first_index = first_index;
   a.total_frames = total;
   a.has_prev = e->frames_seen > 0;
-  int chunks = std::min(e->max_chunks, std::max(1, nframes / 32));
+  int chunks = std::min(e->max_chunks, std::max(1, nframes / 64));
   a.chunk = (nframes + chunks - 1) / chunks;
   chunks = (nframes + a.chunk - 1) / a.chunk;
   a.part = e->d_part;
   const int tb = 256, gx = (n + tb - 1) / tb;
-  hipLaunchKernelGGL(ksa::accumulate_partial_kernel, dim3(gx, chunks), dim3(tb), 0, e->stream, a);
+  const int tb4 = 64, gx4 = (n / 4 + tb4 - 1) / tb4;     // 4 bins per thread
+  hipLaunchKernelGGL(ksa::accumulate_partial_kernel, dim3(gx4, chunks), dim3(tb4), 0, e->stream, a);
   const int owns_last = first_index + nframes == total;
   hipLaunchKernelGGL(ksa::accumulate_reduce_kernel, dim3(gx), dim3(tb), 0, e->stream, e->d_part, chunks, n,
                      db + (long long)(nframes - 1) * n, owns_last, e->d_partial);
@@ -346,6 +357,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   if (n <= 16384) {
     e->path = 0;
     const int pt = 16, lpt = 4;   // 16 points per thread, radix-16 passes (an 8-point / radix-8 plan measured 20 % slower)
+    const bool fused = tune_fused(n);   // table layout must match ksa::Tune<N>::FUSED
     // twiddles in double, stored as float: middle passes [pt-1][p] each, last pass [pt-1][N/pt]
     const int log2n = ksa::ilog2(n);
     const int m = (log2n + lpt - 1) / lpt;
@@ -354,11 +366,24 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     int pcur = r0;
     for (int s = 1; s < m; ++s) {
       std::vector<float2>& dst = s < m - 1 ? mid : last;
-      for (int t = 1; t < pt; ++t)
-        for (int k = 0; k < pcur; ++k) {
-          const double ang = -2.0 * M_PI * (double)t * (double)k / ((double)pcur * pt);
-          dst.push_back(make_float2((float)std::cos(ang), (float)std::sin(ang)));
-        }
+      if (fused) {
+        // rows of dft16_fused: w^4, w^8, w^12, then c[n2][k1] = w^n2 * W16^(n2*k1) for k1 = 0..3, n2 = 1..3
+        for (int e = 0; e < 15; ++e)
+          for (int k = 0; k < pcur; ++k) {
+            const double base = (double)k / ((double)pcur * 16.0);
+            double turns;
+            if (e < 3) turns = 4.0 * (e + 1) * base;
+            else { const int k1 = (e - 3) / 3, n2 = (e - 3) % 3 + 1; turns = n2 * base + (double)(n2 * k1) / 16.0; }
+            const double ang = -2.0 * M_PI * turns;
+            dst.push_back(make_float2((float)std::cos(ang), (float)std::sin(ang)));
+          }
+      } else {
+        for (int t = 1; t < pt; ++t)
+          for (int k = 0; k < pcur; ++k) {
+            const double ang = -2.0 * M_PI * (double)t * (double)k / ((double)pcur * pt);
+            dst.push_back(make_float2((float)std::cos(ang), (float)std::sin(ang)));
+          }
+      }
       pcur *= pt;
     }
     if ((rc = upload(&e->d_tw_mid, mid.data(), mid.size()))) return bail(rc);
@@ -385,7 +410,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   }
 
   const size_t nn = (size_t)n;
-  e->max_chunks = (int)std::max<size_t>(1, std::min<size_t>(256, (64u << 20) / (3 * nn * 4)));
+  e->max_chunks = (int)std::max<size_t>(1, std::min<size_t>(128, (64u << 20) / (3 * nn * 4)));
   hipError_t he;
 #define ALLOC(ptr, bytes)                                                        \
   if ((he = hipMalloc(reinterpret_cast<void**>(&(ptr)), (bytes))) != hipSuccess) \

@@ -124,6 +124,45 @@ __device__ __forceinline__ void dft16_tw(float2 (&v)[16], float2 w1, float2 w2, 
   dft4<12, 1>(v);
 }
 
+// ---- FMA-fused forms -------------------------------------------------------------------------------
+// a + u*b as four FMAs; the matching a - u*b is 2a - (a + u*b): two more instead of four.
+__device__ __forceinline__ float2 cfma(float2 a, float2 u, float2 b) {
+  return make_float2(fmaf(-u.y, b.y, fmaf(u.x, b.x, a.x)), fmaf(u.y, b.x, fmaf(u.x, b.y, a.y)));
+}
+__device__ __forceinline__ float2 twice_minus(float2 a, float2 s) {
+  return make_float2(fmaf(2.0f, a.x, -s.x), fmaf(2.0f, a.y, -s.y));
+}
+
+// radix-4 of (a0, u1*a1, u2*a2, u3*a3) in 24 VALU ops (plain: 12 for the products + 16)
+template <int BASE, int STRIDE, int SZ>
+__device__ __forceinline__ void dft4_tw(float2 (&v)[SZ], float2 u1, float2 u2, float2 u3) {
+  const float2 a0 = v[BASE], a1 = v[BASE + STRIDE], a2 = v[BASE + 2 * STRIDE], a3 = v[BASE + 3 * STRIDE];
+  const float2 s02 = cfma(a0, u2, a2);
+  const float2 d02 = twice_minus(a0, s02);
+  const float2 t1 = cmul(a1, u1);
+  const float2 s13 = cfma(t1, u3, a3);
+  const float2 d13 = twice_minus(t1, s13);
+  v[BASE] = cadd(s02, s13);
+  v[BASE + 2 * STRIDE] = csub(s02, s13);
+  v[BASE + STRIDE] = make_float2(d02.x + d13.y, d02.y - d13.x);      // d02 - j*d13
+  v[BASE + 3 * STRIDE] = make_float2(d02.x - d13.y, d02.y + d13.x);  // d02 + j*d13
+}
+
+// radix-16 of (w^t * v[t]), t = 4*n1 + n2, with all twiddles folded into the two radix-4 levels:
+// level A uses w^4, w^8, w^12; level B uses c[n2][k1] = w^n2 * W16^(n2*k1).  tw[] holds them in the
+// order {w4, w8, w12, c10, c20, c30, c11, c21, c31, c12, c22, c32, c13, c23, c33} (c<n2><k1>).
+// 192 VALU ops instead of 256 for "multiply then transform".  Position P ends up holding X[perm16(P)].
+__device__ __forceinline__ void dft16_fused(float2 (&v)[16], const float2 (&tw)[15]) {
+  dft4_tw<0, 4>(v, tw[0], tw[1], tw[2]);
+  dft4_tw<1, 4>(v, tw[0], tw[1], tw[2]);
+  dft4_tw<2, 4>(v, tw[0], tw[1], tw[2]);
+  dft4_tw<3, 4>(v, tw[0], tw[1], tw[2]);
+  dft4_tw<0, 1>(v, tw[3], tw[4], tw[5]);
+  dft4_tw<4, 1>(v, tw[6], tw[7], tw[8]);
+  dft4_tw<8, 1>(v, tw[9], tw[10], tw[11]);
+  dft4_tw<12, 1>(v, tw[12], tw[13], tw[14]);
+}
+
 // output index held at register position P after the in-place transforms above
 template <int R>
 __host__ __device__ constexpr int perm(int p) {

@@ -162,6 +162,21 @@ struct Tune {
 #else
   static constexpr int WPS = Plan<N>::T >= 512 ? 4 : 3;
 #endif
+  // radix-16 passes with all 15 twiddles folded into FMA-fused radix-4 levels (192 instead of 256 VALU
+  // ops per pass) where the 30 twiddle registers fit without spills; 6-twiddle form otherwise.
+#ifdef KSA_FUSED
+  static constexpr bool FUSED = KSA_FUSED;
+#else
+  static constexpr bool FUSED = Plan<N>::T <= 256;
+#endif
+  // window taps: in LDS ([4][L][4] floats, four ds_read_b128 per window) where three workgroups per CU
+  // leave the room (T <= 256), in VGPRs otherwise.  Frees 16 VGPRs for the fused-twiddle radix-16.
+#ifdef KSA_WIN_LDS
+  static constexpr bool WIN_LDS = KSA_WIN_LDS;
+#else
+  static constexpr bool WIN_LDS = Plan<N>::T <= 256;
+#endif
+  static constexpr int LDS_BYTES = Plan<N>::LDS_BYTES + (WIN_LDS ? N * 4 : 0);
   // prefetch only on the general path: with sample reuse the carried half plus a prefetched half spill
   static constexpr bool pf(int rm) {
 #ifdef KSA_PREFETCH
@@ -190,31 +205,38 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   const int l = tid - slot * L;
   float2* const my = lds + slot * NPAD;
 
-  // ---- per-thread constants: window taps and last-pass twiddles stay in VGPRs ----------------
+  // ---- per-thread constants: window taps (VGPRs or LDS) and last-pass twiddles (VGPRs) --------
+  constexpr bool WIN_LDS = Tune<N>::WIN_LDS;
+  float* const win_lds = reinterpret_cast<float*>(tw_lds + P::MID);   // [4][L][4] floats, shared by the slots
   float win[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) win[q] = p.window[l + L * q];
-  float wof[16];  // only live for the uint8 format
-  if constexpr (FMT == FMT_U8) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      wof[q] = -win[q] * p.u8_offset * p.u8_inv_scale;
-      win[q] = win[q] * p.u8_inv_scale;
+  if constexpr (WIN_LDS) {
+    for (int i = tid; i < N; i += T) {       // tap of sample n = l' + L*q lives at ((q>>2)*L + l')*4 + (q&3)
+      const int q = i / L, ll = i - q * L;
+      win_lds[((q >> 2) * L + ll) * 4 + (q & 3)] = p.window[i] * (FMT == FMT_U8 ? p.u8_inv_scale : 1.0f);
     }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) win[q] = p.window[l + L * q] * (FMT == FMT_U8 ? p.u8_inv_scale : 1.0f);
   }
-  // last pass: k = l, twiddle base w = e^{-2*pi*i*l/N}; rows t = 1,2,3,4,8,12 of the [15][N/16] table
-  float2 w1, w2, w3, w4, w8, w12;
+  // last pass: k = l.  FUSED: the 15 folded twiddles of dft16_fused (rows of the [15][N/16] table);
+  // otherwise rows t = 1,2,3,4,8,12 of the plain w^t table for dft16_tw.
+  constexpr bool FUSED = Tune<N>::FUSED;
+  float2 twl[FUSED ? 15 : 6];
   if constexpr (M >= 2) {
-    w1 = p.tw_last[0 * P::P_LAST + l];
-    w2 = p.tw_last[1 * P::P_LAST + l];
-    w3 = p.tw_last[2 * P::P_LAST + l];
-    w4 = p.tw_last[3 * P::P_LAST + l];
-    w8 = p.tw_last[7 * P::P_LAST + l];
-    w12 = p.tw_last[11 * P::P_LAST + l];
+    if constexpr (FUSED) {
+#pragma unroll
+      for (int e = 0; e < 15; ++e) twl[e] = p.tw_last[e * P::P_LAST + l];
+    } else {
+      constexpr int rows[6] = {0, 1, 2, 3, 7, 11};
+#pragma unroll
+      for (int e = 0; e < 6; ++e) twl[e] = p.tw_last[rows[e] * P::P_LAST + l];
+    }
   }
   if constexpr (P::MID > 0) {
     for (int i = tid; i < P::MID; i += T) tw_lds[i] = p.tw_mid[i];
   }
+
+  if constexpr (WIN_LDS) __syncthreads();   // taps are read before the first exchange barrier
 
   const int rounds = (p.nwin + S - 1) / S;
   const int nm1 = p.nwin - 1;
@@ -271,6 +293,13 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       float2 v[16];
       if (!PF && active) issue_loads(frame, frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
       if (active) {
+        if constexpr (WIN_LDS) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 w4 = reinterpret_cast<const float4*>(win_lds)[q4 * L + l];
+            win[4 * q4 + 0] = w4.x; win[4 * q4 + 1] = w4.y; win[4 * q4 + 2] = w4.z; win[4 * q4 + 3] = w4.w;
+          }
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           if constexpr (FMT == FMT_C64) {
@@ -278,9 +307,9 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
             const unsigned xr = raw[q].x, xi = raw[q].y;
             v[(q % B0) * R0 + (q / B0)] = make_float2(__uint_as_float(xr) * win[q], __uint_as_float(xi) * win[q]);
           } else {
-            const unsigned short x = raw[q];
-            v[(q % B0) * R0 + (q / B0)] = make_float2(fmaf((float)(x & 0xff), win[q], wof[q]),
-                                                      fmaf((float)(x >> 8), win[q], wof[q]));
+            const unsigned short x = raw[q];   // (b - offset)/scale * w, taps pre-divided by the scale
+            v[(q % B0) * R0 + (q / B0)] = make_float2(((float)(x & 0xff) - p.u8_offset) * win[q],
+                                                      ((float)(x >> 8) - p.u8_offset) * win[q]);
           }
         }
       }
@@ -323,11 +352,23 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
           if (active) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) KSA_LDS_LD(v[t], my[padi(l + L * t)]);
-            if (s < M - 1) {
-              const float2* tw = tw_lds + tw_off + (l & (pp - 1));
-              dft16_tw(v, tw[0], tw[pp], tw[2 * pp], tw[3 * pp], tw[7 * pp], tw[11 * pp]);
+            if constexpr (FUSED) {
+              if (s < M - 1) {
+                const float2* tw = tw_lds + tw_off + (l & (pp - 1));
+                float2 tm[15];
+#pragma unroll
+                for (int e = 0; e < 15; ++e) tm[e] = tw[e * pp];
+                dft16_fused(v, tm);
+              } else {
+                dft16_fused(v, reinterpret_cast<const float2(&)[15]>(twl));
+              }
             } else {
-              dft16_tw(v, w1, w2, w3, w4, w8, w12);
+              if (s < M - 1) {
+                const float2* tw = tw_lds + tw_off + (l & (pp - 1));
+                dft16_tw(v, tw[0], tw[pp], tw[2 * pp], tw[3 * pp], tw[7 * pp], tw[11 * pp]);
+              } else {
+                dft16_tw(v, twl[0], twl[1], twl[2], twl[3], twl[4], twl[5]);
+              }
             }
           }
           KSA_STAMP(s < M - 1 ? 4 : 6);
@@ -443,28 +484,36 @@ struct AccParams {
 __device__ __forceinline__ float nan_max(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
 __device__ __forceinline__ float nan_min(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fminf(a, b); }
 
+// One thread = 4 consecutive bins (16-byte loads), one blockIdx.y = one chunk of frames.
 __global__ void accumulate_partial_kernel(const AccParams p) {
-  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bin >= p.n) return;
+  const int b4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b4 * 4 >= p.n) return;
   const int c = blockIdx.y;
   const int f0 = c * p.chunk;
   const int f1 = min(p.nframes, f0 + p.chunk);
-  float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.f;
+  const float ninf = -__builtin_inff(), pinf = __builtin_inff();
+  float mx[4] = {ninf, ninf, ninf, ninf}, mn[4] = {pinf, pinf, pinf, pinf}, sum[4] = {0.f, 0.f, 0.f, 0.f};
+  const float4* src = reinterpret_cast<const float4*>(p.db) + b4;
+  const long long stride4 = p.n / 4;
+#pragma unroll 4
   for (int f = f0; f < f1; ++f) {
-    const float x = p.db[(long long)f * p.n + bin];
-    mx = nan_max(mx, x);
-    mn = nan_min(mn, x);
+    const float4 x4 = src[(long long)f * stride4];
     const long long kg = p.first_index + f;
     long long e = p.total_frames - kg;            // 2^-(n-k+1) with n = total-1
     if (kg == 0 && !p.has_prev) e = p.total_frames - 1;
     const float w = e > 160 ? 0.f : ldexpf(1.0f, -(int)e);
-    const bool fin = fabsf(x) < __builtin_inff();
-    sum += fin ? w * x : x;
+    const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      mx[u] = nan_max(mx[u], x[u]);
+      mn[u] = nan_min(mn[u], x[u]);
+      sum[u] += fabsf(x[u]) < pinf ? w * x[u] : x[u];
+    }
   }
-  float* o = p.part + (long long)c * 3 * p.n;
-  o[bin] = mx;
-  o[p.n + bin] = mn;
-  o[2 * p.n + bin] = sum;
+  float4* o = reinterpret_cast<float4*>(p.part + (long long)c * 3 * p.n) + b4;
+  o[0] = make_float4(mx[0], mx[1], mx[2], mx[3]);
+  o[stride4] = make_float4(mn[0], mn[1], mn[2], mn[3]);
+  o[2 * stride4] = make_float4(sum[0], sum[1], sum[2], sum[3]);
 }
 
 // partial block layout: [max | cur-or--inf | min | sum], N floats each
@@ -473,6 +522,7 @@ __global__ void accumulate_reduce_kernel(const float* part, int chunks, int n, c
   const int bin = blockIdx.x * blockDim.x + threadIdx.x;
   if (bin >= n) return;
   float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.f;
+#pragma unroll 8
   for (int c = 0; c < chunks; ++c) {
     const float* o = part + (long long)c * 3 * n;
     mx = nan_max(mx, o[bin]);
