@@ -85,3 +85,52 @@ class ShardedZeroSpan:
         merge_ring(self._ring, self.hm_index, frames, self.world, self.group)
         self.hm_index = (self.hm_index + total) % HM_ROWS
         eng.set_hm_index(self.hm_index)
+
+
+# ------------------------------------------------------------------------------------------------
+# Frequency-band sharding of a scan pass (BASELINE config 4)
+def step_range(nsteps, rank, world):
+    """Contiguous, balanced share of the tuned bands of one pass: [lo, hi)."""
+    lo = (nsteps * rank) // world
+    hi = (nsteps * (rank + 1)) // world
+    return lo, hi
+
+
+def gather_steps(local, nsteps, rank, world, group=None):
+    """local: float32[hi-lo, N] per-step spectra of this rank's bands -> float32[nsteps, N] on every rank.
+    Shares differ by at most one step, so every rank pads to the largest share for one all_gather."""
+    if world == 1:
+        return local
+    n = local.shape[1]
+    most = max(step_range(nsteps, r, world)[1] - step_range(nsteps, r, world)[0] for r in range(world))
+    pad = torch.zeros((most, n), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.empty((nsteps, n), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        lo, hi = step_range(nsteps, r, world)
+        out[lo:hi] = parts[r][:hi - lo]
+    return out
+
+
+class ShardedScan:
+    """One scan pass over G GPUs: the steps (tuned bands, each with its own IQ capture) are independent up to
+    their dB spectrum (K:636-641), so rank r transforms steps [lo, hi); one all-gather of float32[steps][N]
+    (153 KiB at quickFullScan, 1.1 MiB at fmScan) hands every rank the whole pass and each rank runs the
+    stitch + Max/Min/Avg + waterfall-row kernels on it (K:643-668, K:696-697) -- identical state everywhere,
+    no second collective."""
+
+    def __init__(self, engine, rank=0, world=1, group=None):
+        self.eng, self.rank, self.world, self.group = engine, rank, world, group
+
+    def run_pass(self, iq_local, fmt, nsteps):
+        """iq_local: this rank's capture blocks, [hi-lo] frames of fullSize samples, on its GPU."""
+        from ._lib import OUT_DB_CLIP
+        eng = self.eng
+        lo, hi = step_range(nsteps, self.rank, self.world)
+        local = torch.empty((max(hi - lo, 1), eng.fft_size), dtype=torch.float32, device="cuda")
+        if hi > lo:
+            eng.curscan_dev(iq_local, fmt, hi - lo, local, out_mode=OUT_DB_CLIP)
+        full = gather_steps(local[:hi - lo], nsteps, self.rank, self.world, self.group)
+        eng.scan_stitch_dev(full.contiguous(), nsteps)

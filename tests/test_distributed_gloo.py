@@ -103,3 +103,35 @@ def test_ring_owner_map():
     assert slots[72 % 128] == 1 or slots[72] == 0
     newest = {(g % 128): g // 100 for g in range(72, 200)}
     assert all(slots[s] == r for s, r in newest.items())
+
+
+# ------------------------------------------------------------------------------------------ scan band shard
+def _scan_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ksa_dist = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
+    n, full, steps = 64, 512, 7                                  # 7 steps over 3 ranks: shares 2/2/3
+    x = orc.synth_iq(full * steps, 77).astype(np.complex64).reshape(steps, full)
+    lo, hi = ksa_dist.step_range(steps, rank, world)
+    win = orc.window_table("ones", n)
+    local = np.array([orc.curscan(x[s], n, 0.1, win, "AVG") for s in range(lo, hi)], dtype=np.float32).reshape(hi - lo, n)
+    got = ksa_dist.gather_steps(torch.from_numpy(local), steps, rank, world)
+    if rank == world - 1:
+        np.save(out_path, got.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scan_band_shard_gather(tmp_path):
+    load_pkg()
+    ksa_dist = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
+    assert [ksa_dist.step_range(7, r, 3) for r in range(3)] == [(0, 2), (2, 4), (4, 7)]
+    assert [ksa_dist.step_range(1226, r, 8)[1] - ksa_dist.step_range(1226, r, 8)[0] for r in range(8)] == [153, 153, 153, 154, 153, 153, 153, 154]
+    out = str(tmp_path / "steps.npy")
+    mp.spawn(_scan_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    n, full, steps = 64, 512, 7
+    x = orc.synth_iq(full * steps, 77).astype(np.complex64).reshape(steps, full)
+    want = np.array([orc.curscan(x[s], n, 0.1, orc.window_table("ones", n), "AVG") for s in range(steps)], dtype=np.float32)
+    assert np.array_equal(np.load(out), want)

@@ -357,3 +357,24 @@ def test_full_size_batch_properties(ksa, torch_cuda):
     st4 = eng.state()
     assert np.max(np.abs(st4["Fft.Cur"] - st["Fft.Cur"] - 10 * np.log10(4.0))) < 1e-4
     eng.close()
+
+
+def test_sharded_scan_driver_world1(ksa, torch_cuda):
+    """distributed.ShardedScan on one rank: per-step clipped dB spectra -> scan_stitch_dev == scan_pass_dev."""
+    torch = torch_cuda
+    dmod = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
+    g = golden("scan_quick_n64")
+    n, full = int(g["fft_size"]), int(g["full"])
+    passes, steps = int(g["passes"]), int(g["steps"])
+    groups = int((float(g["end_freq"]) - float(g["start_freq"])) / float(g["sampling_rate"]))
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=float(g["non_overlap"]), window=str(g["window"]),
+                             gain=float(g["gain"]), min_amp=float(g["min_amp"]), xres=int(g["xres"]),
+                             max_frames=steps, scan_total_entries=groups * n)
+    x = torch.view_as_real(torch.from_numpy(g["iq"].reshape(passes, steps, full))).cuda()
+    run = dmod.ShardedScan(eng)
+    for p in range(passes):
+        run.run_pass(x[p], ksa.FMT_C64, steps)
+    st = eng.scan_state()
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], g[k], what="sharded scan " + k)
+    eng.close()
