@@ -254,7 +254,7 @@ int run_accumulate(ksa_engine* e, const float* db, int nframes, long long first_
   const int tb4 = 64, gx4 = (n / 4 + tb4 - 1) / tb4;     // 4 bins per thread
   hipLaunchKernelGGL(ksa::accumulate_partial_kernel, dim3(gx4, chunks), dim3(tb4), 0, e->stream, a);
   const int owns_last = first_index + nframes == total;
-  hipLaunchKernelGGL(ksa::accumulate_reduce_kernel, dim3(gx), dim3(tb), 0, e->stream, e->d_part, chunks, n,
+  hipLaunchKernelGGL(ksa::accumulate_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, e->stream, e->d_part, chunks, n,
                      db + (long long)(nframes - 1) * n, owns_last, e->d_partial);
   HIP_OK(hipGetLastError());
   return 0;

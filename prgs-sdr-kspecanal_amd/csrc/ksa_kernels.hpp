@@ -516,23 +516,40 @@ __global__ void accumulate_partial_kernel(const AccParams p) {
   o[2 * stride4] = make_float4(sum[0], sum[1], sum[2], sum[3]);
 }
 
-// partial block layout: [max | cur-or--inf | min | sum], N floats each
-__global__ void accumulate_reduce_kernel(const float* part, int chunks, int n, const float* last_db,
-                                         int owns_last, float* partial) {
-  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bin >= n) return;
+// partial block layout: [max | cur-or--inf | min | sum], N floats each.
+// Workgroup = 64 bins x 16 chunk groups (1024 threads): every thread folds chunks/16 partials, the 16
+// groups are combined through LDS in chunk order, so the short dependent chains run in parallel.
+__global__ __launch_bounds__(1024) void accumulate_reduce_kernel(const float* part, int chunks, int n, const float* last_db,
+                                                                 int owns_last, float* partial) {
+  __shared__ float sh[3][16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int bin = blockIdx.x * 64 + lane;
   float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.f;
-#pragma unroll 8
-  for (int c = 0; c < chunks; ++c) {
-    const float* o = part + (long long)c * 3 * n;
-    mx = nan_max(mx, o[bin]);
-    mn = nan_min(mn, o[n + bin]);
-    sum += o[2 * n + bin];
+  const int per = (chunks + 15) / 16;
+  const int c0 = grp * per, c1 = min(chunks, c0 + per);
+  if (bin < n) {
+    for (int c = c0; c < c1; ++c) {
+      const float* o = part + (long long)c * 3 * n;
+      mx = nan_max(mx, o[bin]);
+      mn = nan_min(mn, o[n + bin]);
+      sum += o[2 * n + bin];
+    }
   }
-  partial[bin] = mx;
-  partial[n + bin] = owns_last ? last_db[bin] : -__builtin_inff();
-  partial[2 * n + bin] = mn;
-  partial[3 * n + bin] = sum;
+  sh[0][grp][lane] = mx;
+  sh[1][grp][lane] = mn;
+  sh[2][grp][lane] = sum;
+  __syncthreads();
+  if (grp == 0 && bin < n) {
+    for (int g = 1; g < 16; ++g) {
+      mx = nan_max(mx, sh[0][g][lane]);
+      mn = nan_min(mn, sh[1][g][lane]);
+      sum += sh[2][g][lane];
+    }
+    partial[bin] = mx;
+    partial[n + bin] = owns_last ? last_db[bin] : -__builtin_inff();
+    partial[2 * n + bin] = mn;
+    partial[3 * n + bin] = sum;
+  }
 }
 
 // state layout: [cur | max | min | avg]
