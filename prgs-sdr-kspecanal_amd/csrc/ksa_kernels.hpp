@@ -176,6 +176,13 @@ struct Tune {
 #else
   static constexpr bool WIN_LDS = Plan<N>::T <= 256;
 #endif
+  // T >= 512 (LDS full, 128-VGPR cap): taps are re-read from the L2-resident table with every window's
+  // IQ loads instead of living in 16 VGPRs
+#ifdef KSA_WIN_GLOBAL
+  static constexpr bool WIN_GLOBAL = KSA_WIN_GLOBAL;
+#else
+  static constexpr bool WIN_GLOBAL = Plan<N>::T >= 512;
+#endif
   static constexpr int LDS_BYTES = Plan<N>::LDS_BYTES + (WIN_LDS ? N * 4 : 0);
   // prefetch only on the general path: with sample reuse the carried half plus a prefetched half spill
   static constexpr bool pf(int rm) {
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       const int q = i / L, ll = i - q * L;
       win_lds[((q >> 2) * L + ll) * 4 + (q & 3)] = p.window[i] * (FMT == FMT_U8 ? p.u8_inv_scale : 1.0f);
     }
-  } else {
+  } else if constexpr (!Tune<N>::WIN_GLOBAL) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) win[q] = p.window[l + L * q] * (FMT == FMT_U8 ? p.u8_inv_scale : 1.0f);
   }
@@ -293,6 +300,13 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       float2 v[16];
       if (!PF && active) issue_loads(frame, frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
       if (active) {
+        if constexpr (!WIN_LDS && Tune<N>::WIN_GLOBAL) {
+          // scalar descriptor + scalar offsets: no per-load address VGPRs
+          const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.window), 0, N * 4, 0x00020000);
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            win[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, l * 4, L * q * 4, 0)) * (FMT == FMT_U8 ? p.u8_inv_scale : 1.0f);
+        }
         if constexpr (WIN_LDS) {
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {

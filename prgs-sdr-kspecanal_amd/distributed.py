@@ -45,8 +45,6 @@ def ring_owner(idx0, frames_per_rank, world):
 
 def merge_ring(ring, idx0, frames_per_rank, world, group=None):
     """ring: float32[128, W] of this rank (rows written at globally correct slots), merged in place."""
-    if world == 1:
-        return ring
     gathered = [torch.empty_like(ring) for _ in range(world)]
     dist.all_gather(gathered, ring.contiguous(), group=group)
     owner = ring_owner(idx0, frames_per_rank, world).to(ring.device)
@@ -61,10 +59,11 @@ def merge_ring(ring, idx0, frames_per_rank, world, group=None):
 class ShardedZeroSpan:
     """Drives one engine per rank; with world == 1 it is a plain frames_dev call."""
 
-    def __init__(self, engine, rank=0, world=1, group=None):
+    def __init__(self, engine, rank=0, world=1, group=None, always_collective=False):
         self.eng, self.rank, self.world, self.group = engine, rank, world, group
         self.hm_index = 0                              # global ring position (identical on all ranks)
-        if world > 1:
+        self.collective = world > 1 or always_collective   # always_collective: run the merge path on one rank too
+        if self.collective:
             self._partial = torch.as_tensor(engine.partial(), device="cuda")
             _, ring = engine.state_dev()
             self._ring = torch.as_tensor(ring, device="cuda")
@@ -72,7 +71,7 @@ class ShardedZeroSpan:
     def step(self, iq, fmt, frames, cur_db=None, hm_rows=None):
         """Every rank passes its own `frames` capture blocks (its time chunk of a world*frames run)."""
         eng = self.eng
-        if self.world == 1:
+        if not self.collective:
             eng.frames_dev(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
             self.hm_index = (self.hm_index + frames) % HM_ROWS
             return

@@ -378,3 +378,35 @@ def test_sharded_scan_driver_world1(ksa, torch_cuda):
     for k in ("cur", "max", "min", "avg"):
         assert_db(st["Fft." + k.capitalize()], g[k], what="sharded scan " + k)
     eng.close()
+
+
+def test_rccl_merge_path_single_rank(ksa, torch_cuda):
+    """The multi-GPU merge of distributed.ShardedZeroSpan (views of library memory as torch tensors, RCCL
+    all-reduce / all-gather, ksa_commit) driven on a one-rank nccl group must equal the plain path."""
+    import os
+    import torch.distributed as dist
+    torch = torch_cuda
+    dmod = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, full, frames = 1024, 8192, 300
+        x = orc.synth_iq(full * 64, 808).astype(np.complex64).reshape(64, full)
+        dev = torch.view_as_real(torch.from_numpy(x)).cuda().repeat(5, 1, 1)[:frames].contiguous()
+        states = []
+        for coll in (False, True):
+            eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", max_frames=frames,
+                                     stream=torch.cuda.current_stream().cuda_stream)
+            run = dmod.ShardedZeroSpan(eng, 0, 1, always_collective=coll)
+            run.step(dev, ksa.FMT_C64, frames)
+            run.step(dev[:77], ksa.FMT_C64, 77)
+            torch.cuda.synchronize()
+            states.append(eng.state())
+            eng.close()
+        a, b = states
+        assert a["frames"] == b["frames"] == 377 and a["hm_index"] == b["hm_index"] == 377 % 128
+        for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg", "fftHM"):
+            assert np.array_equal(a[k], b[k]), k
+    finally:
+        dist.destroy_process_group()
