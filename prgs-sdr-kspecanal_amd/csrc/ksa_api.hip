@@ -37,13 +37,21 @@ int fail(const char* fmt, ...) {
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-// host mirror of ksa::Tune<N>::FUSED (the twiddle table layout depends on it)
+// host mirrors of ksa::Tune<N>::FUSED / FUSED_LAST (the twiddle table layouts depend on them)
 bool tune_fused(int n) {
 #ifdef KSA_FUSED
   (void)n;
   return KSA_FUSED;
 #else
   return n <= 4096;
+#endif
+}
+bool tune_fused_last(int n) {
+#ifdef KSA_FUSED_LAST
+  (void)n;
+  return KSA_FUSED_LAST;
+#else
+  return tune_fused(n);
 #endif
 }
 
@@ -111,7 +119,12 @@ int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
     }
     return 0;
   }
-  const int grid = std::max(1, std::min(p.nframes, e->num_cu * e->blocks_per_cu));
+  int grid = std::max(1, std::min(p.nframes, e->num_cu * e->blocks_per_cu));
+  // the prefetch path addresses the next frame (frame + grid) through the current frame's 32-bit
+  // buffer offsets: keep (grid*stride + fullSize) * sample_bytes below 2^31
+  const long long sb = FMT == ksa::FMT_C64 ? 8 : 2;
+  const long long room = ((1ll << 31) - 1) / sb - p.frame_len;
+  if (p.frame_stride > 0 && (long long)grid * p.frame_stride > room) grid = (int)std::max<long long>(1, room / p.frame_stride);
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), ksa::Tune<N>::LDS_BYTES, e->stream, p);
   HIP_OK(hipGetLastError());
   return 0;
@@ -168,6 +181,7 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
   if (fmt != KSA_FMT_C64 && fmt != KSA_FMT_U8) return fail("unknown sample format %d", fmt);
   if (nframes < 1 || nframes > c.max_frames) return fail("nframes %d outside 1..max_frames(%d)", nframes, c.max_frames);
   if (stride < 0) return fail("negative frame_stride");
+  if (stride > (1ll << 27)) return fail("frame_stride %lld exceeds 2^27 samples", stride);
   // the output stage stores float4 runs; IQ loads are per-sample but frames should start on sample bounds
   if ((reinterpret_cast<uintptr_t>(out) & 15) || (hm_rows && (reinterpret_cast<uintptr_t>(hm_rows) & 15)))
     return fail("device output buffers must be 16-byte aligned");
@@ -357,7 +371,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   if (n <= 16384) {
     e->path = 0;
     const int pt = 16, lpt = 4;   // 16 points per thread, radix-16 passes (an 8-point / radix-8 plan measured 20 % slower)
-    const bool fused = tune_fused(n);   // table layout must match ksa::Tune<N>::FUSED
+    const bool fused_mid = tune_fused(n), fused_last = tune_fused_last(n);   // layouts must match ksa::Tune<N>
     // twiddles in double, stored as float: middle passes [pt-1][p] each, last pass [pt-1][N/pt]
     const int log2n = ksa::ilog2(n);
     const int m = (log2n + lpt - 1) / lpt;
@@ -366,6 +380,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     int pcur = r0;
     for (int s = 1; s < m; ++s) {
       std::vector<float2>& dst = s < m - 1 ? mid : last;
+      const bool fused = s < m - 1 ? fused_mid : fused_last;
       if (fused) {
         // rows of dft16_fused: w^4, w^8, w^12, then c[n2][k1] = w^n2 * W16^(n2*k1) for k1 = 0..3, n2 = 1..3
         for (int e = 0; e < 15; ++e)

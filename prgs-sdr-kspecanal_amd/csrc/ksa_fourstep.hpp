@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "ksa_kernels.hpp"
@@ -316,7 +317,9 @@ inline int fourstep_create(FourStep& f, int n, int nwin, int max_frames, int /*n
   if (fs_upload(&f.d_tw_big, big)) return 1;
   // scratch budget 1 GiB (at least one frame)
   const size_t per_frame = (size_t)nwin * n * sizeof(float2);
-  size_t cf = std::max<size_t>(1, ((size_t)1 << 30) / per_frame);
+  size_t budget = (size_t)1 << 30;
+  if (const char* mb = getenv("KSA_FS_SCRATCH_MB")) budget = (size_t)atol(mb) << 20;   // A/B switch for measurements
+  size_t cf = std::max<size_t>(1, budget / per_frame);
   f.chunk_frames = (int)std::min<size_t>(cf, (size_t)max_frames);
   if (hipMalloc(reinterpret_cast<void**>(&f.d_z), per_frame * f.chunk_frames) != hipSuccess) return 1;
   FourParams fp{};

@@ -169,6 +169,12 @@ struct Tune {
 #else
   static constexpr bool FUSED = Plan<N>::T <= 256;
 #endif
+  // the last pass keeps its twiddles in VGPRs: 30 for the fused form, 12 for the 6-twiddle form
+#ifdef KSA_FUSED_LAST
+  static constexpr bool FUSED_LAST = KSA_FUSED_LAST;
+#else
+  static constexpr bool FUSED_LAST = FUSED;
+#endif
   // window taps: in LDS ([4][L][4] floats, four ds_read_b128 per window) where three workgroups per CU
   // leave the room (T <= 256), in VGPRs otherwise.  Frees 16 VGPRs for the fused-twiddle radix-16.
 #ifdef KSA_WIN_LDS
@@ -227,10 +233,10 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   }
   // last pass: k = l.  FUSED: the 15 folded twiddles of dft16_fused (rows of the [15][N/16] table);
   // otherwise rows t = 1,2,3,4,8,12 of the plain w^t table for dft16_tw.
-  constexpr bool FUSED = Tune<N>::FUSED;
-  float2 twl[FUSED ? 15 : 6];
+  constexpr bool FUSED = Tune<N>::FUSED, FUSED_LAST = Tune<N>::FUSED_LAST;
+  float2 twl[FUSED_LAST ? 15 : 6];
   if constexpr (M >= 2) {
-    if constexpr (FUSED) {
+    if constexpr (FUSED_LAST) {
 #pragma unroll
       for (int e = 0; e < 15; ++e) twl[e] = p.tw_last[e * P::P_LAST + l];
     } else {
@@ -253,6 +259,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   // remaining passes (plain VMEM loads stay in flight across s_barrier).
   typedef typename std::conditional<FMT == FMT_C64, u32x2, unsigned short>::type raw_t;
   raw_t raw[16];
+  const int start0 = p.starts[0];
   // Loads of window k of frame `fr`, addressed relative to the wave-uniform frame `base_fr` so that the
   // buffer descriptor is built from scalars only (a per-lane descriptor makes hipcc wrap every load in
   // a readfirstlane "waterfall" loop).  The descriptor spans base_fr .. base_fr + gridDim.x frames
@@ -263,7 +270,9 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
     if (span > (int)gridDim.x) span = gridDim.x;
     const long long bytes = ((long long)span * p.frame_stride + p.frame_len) * SB;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fbase), 0, (int)bytes, 0x00020000);
-    const int voff = ((fr - base_fr) * (int)p.frame_stride + p.starts[k] + l) * SB;
+    // reuse path: hops are constant (RM*L samples), so the start is arithmetic -- no dependent scalar load
+    const int start = RM > 0 ? start0 + k * (RM * L) : p.starts[k];
+    const int voff = ((fr - base_fr) * (int)p.frame_stride + start + l) * SB;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       if (q < q0) continue;
@@ -366,23 +375,19 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
           if (active) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) KSA_LDS_LD(v[t], my[padi(l + L * t)]);
-            if constexpr (FUSED) {
-              if (s < M - 1) {
-                const float2* tw = tw_lds + tw_off + (l & (pp - 1));
+            if (s < M - 1) {
+              const float2* tw = tw_lds + tw_off + (l & (pp - 1));
+              if constexpr (FUSED) {
                 float2 tm[15];
 #pragma unroll
                 for (int e = 0; e < 15; ++e) tm[e] = tw[e * pp];
                 dft16_fused(v, tm);
               } else {
-                dft16_fused(v, reinterpret_cast<const float2(&)[15]>(twl));
+                dft16_tw(v, tw[0], tw[pp], tw[2 * pp], tw[3 * pp], tw[7 * pp], tw[11 * pp]);
               }
             } else {
-              if (s < M - 1) {
-                const float2* tw = tw_lds + tw_off + (l & (pp - 1));
-                dft16_tw(v, tw[0], tw[pp], tw[2 * pp], tw[3 * pp], tw[7 * pp], tw[11 * pp]);
-              } else {
-                dft16_tw(v, twl[0], twl[1], twl[2], twl[3], twl[4], twl[5]);
-              }
+              if constexpr (FUSED_LAST) dft16_fused(v, reinterpret_cast<const float2(&)[15]>(twl));
+              else dft16_tw(v, twl[0], twl[1], twl[2], twl[3], twl[4], twl[5]);
             }
           }
           KSA_STAMP(s < M - 1 ? 4 : 6);
