@@ -124,6 +124,9 @@ int ksa_scan_read_state(ksa_engine* e, float* cur, float* max, float* min, float
                         int32_t* hm_index, int64_t* passes);
 int ksa_scan_state_dev(ksa_engine* e, float** state_dev, float** hm_ring_dev);
 int ksa_scan_reset(ksa_engine* e);
+/* d['bScanRangeBaseDataIsRaw'] (K:568, K:651-662): Max/Min/Avg fold every tuned band's own spectrum over
+ * [iStart:iEnd] instead of the stitched Fft.Cur over [iStart:iDone]. */
+int ksa_scan_set_base_is_raw(ksa_engine* e, int32_t on);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event timing of the spectrum kernel on the engine's stream: enable, run, then read the sum

@@ -84,6 +84,7 @@ struct ksa_engine {
   int hm_index = 0;
   int pending_frames = 0;       // frames of the last uncommitted batch
   int b_max = 1, b_min = 1, b_avg = 1;
+  int scan_base_is_raw = 0;
   long long scan_passes = 0;
   int scan_hm_index = 0;
   int max_chunks = 1;
@@ -643,6 +644,7 @@ int ksa_scan_stitch_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps)
   s.first_pass = e->scan_passes == 0;
   s.b_max = e->b_max;
   s.b_min = e->b_min;
+  s.base_is_raw = e->scan_base_is_raw;
   const int tb = 256;
   hipLaunchKernelGGL(ksa::scan_stitch_kernel, dim3((s.total + tb - 1) / tb), dim3(tb), 0, e->stream, s);
   const int g = c.scan_total_entries / c.scan_hm_width;
@@ -690,6 +692,12 @@ int ksa_scan_state_dev(ksa_engine* e, float** state_dev, float** hm_ring_dev) {
   if (!e) return fail("null engine");
   if (state_dev) *state_dev = e->d_scan_state;
   if (hm_ring_dev) *hm_ring_dev = e->d_scan_hm;
+  return 0;
+}
+
+int ksa_scan_set_base_is_raw(ksa_engine* e, int32_t on) {
+  if (!e) return fail("null engine");
+  e->scan_base_is_raw = on != 0;
   return 0;
 }
 

@@ -601,6 +601,7 @@ struct StitchParams {
   float* state;          // [4][total] : cur, max, min, avg
   int first_pass;        // pass 0 seeds Avg by copy (K:615-618)
   int b_max, b_min;
+  int base_is_raw;       // bScanRangeBaseDataIsRaw (K:651-656): Max/Min/Avg see every covering step's own spectrum
 };
 
 __global__ void scan_stitch_kernel(const StitchParams p) {
@@ -615,9 +616,23 @@ __global__ void scan_stitch_kernel(const StitchParams p) {
   for (int i = i0 + 1; i <= i1; ++i) cur = (cur + p.step_db[(long long)i * p.n + (e - i * p.hop)]) * 0.5f;
   const int tot = p.total;
   p.state[e] = cur;
-  if (p.b_max) p.state[tot + e] = nan_max(p.state[tot + e], cur);
-  if (p.b_min) p.state[2 * tot + e] = nan_min(p.state[2 * tot + e], cur);
-  p.state[3 * tot + e] = p.first_pass ? cur : (p.state[3 * tot + e] + cur) * 0.5f;
+  if (!p.base_is_raw) {
+    if (p.b_max) p.state[tot + e] = nan_max(p.state[tot + e], cur);
+    if (p.b_min) p.state[2 * tot + e] = nan_min(p.state[2 * tot + e], cur);
+    p.state[3 * tot + e] = p.first_pass ? cur : (p.state[3 * tot + e] + cur) * 0.5f;
+  } else {
+    // every covering step, in order, folds its own spectrum in (pass 0: Avg is overwritten by each step)
+    float mx = p.state[tot + e], mn = p.state[2 * tot + e], av = p.state[3 * tot + e];
+    for (int i = i0; i <= i1; ++i) {
+      const float x = p.step_db[(long long)i * p.n + (e - i * p.hop)];
+      mx = nan_max(mx, x);
+      mn = nan_min(mn, x);
+      av = p.first_pass ? x : (av + x) * 0.5f;
+    }
+    if (p.b_max) p.state[tot + e] = mx;
+    if (p.b_min) p.state[2 * tot + e] = mn;
+    p.state[3 * tot + e] = av;
+  }
 }
 
 __global__ void fill_kernel(float* dst, long long n, float v) {

@@ -266,6 +266,9 @@ class SpectrumEngine:
     def scan_reset(self):
         check(lib.ksa_scan_reset(self._h))
 
+    def scan_set_base_is_raw(self, on):
+        check(lib.ksa_scan_set_base_is_raw(self._h, int(bool(on))))
+
     # -- measurement ------------------------------------------------------------------------------------
     def prof_enable(self, on=True):
         check(lib.ksa_prof_enable(self._h, int(on)))

@@ -512,6 +512,7 @@ def scan_range(d):
     steps = len(centers)
     eng = get_engine(d, scan_total=total, max_frames=steps)
     eng.scan_reset()
+    eng.scan_set_base_is_raw(d["bScanRangeBaseDataIsRaw"])
     span = groups * d["samplingRate"]
     d["freqsAll"] = np.fft.fftshift(np.fft.fftfreq(total, 1 / span) + d["startFreq"] + span / 2)   # K:609
     u8 = d["iqFormat"] == "u8" and hasattr(d["sdr"], "read_bytes")

@@ -188,7 +188,9 @@ def main():
             ("frac_n256", ["scan", "startFreq", 88e6, "endFreq", 93e6, "fftSize", 256,
                            "window", "hanning", "prgLoopCnt", 3, "xRes", 64], 2.4e6),
             ("quick_n64", ["scan", "startFreq", 30e6, "endFreq", 54e6, "fftSize", 64,
-                           "prgLoopCnt", 2, "pltCompress", "RAW"], 2.4e6)):
+                           "prgLoopCnt", 2, "pltCompress", "RAW"], 2.4e6),
+            ("baseraw_n256", ["scan", "startFreq", 200e6, "endFreq", 207.2e6, "fftSize", 256, "window", "hamming",
+                              "prgLoopCnt", 3, "xRes", 128, "bScanRangeBaseDataIsRaw", "true"], 2.4e6)):
         n = argv[argv.index("fftSize") + 1]
         passes = argv[argv.index("prgLoopCnt") + 1]
         a, b = argv[argv.index("startFreq") + 1], argv[argv.index("endFreq") + 1]
@@ -209,6 +211,7 @@ def main():
              start_freq=g["startFreq"], end_freq=g["endFreq"], sampling_rate=g["samplingRate"],
              gain=g["gain"], min_amp=g["minAmp4Clip"], xres=g["xRes"], window=g["window"],
              non_overlap=g["curScanNonOverlap"], scan_non_overlap=g["scanRangeNonOverlap"],
+             base_is_raw=g["bScanRangeBaseDataIsRaw"],
              cur=g["Fft.Cur"], max=g["Fft.Max"], min=g["Fft.Min"], avg=g["Fft.Avg"],
              hm=g["fftHM"], hm_index=g["fftHMIndex"])
 

@@ -120,3 +120,29 @@ def test_scan_main(K):
         assert_db(d["Fft." + k], getattr(ref, k.lower()), what="scan " + k)
     assert_db(d["fftHM"][:2], ref.hm[:2], what="scan waterfall")
     assert np.array_equal(d["freqsAll"], np.fft.fftshift(np.fft.fftfreq(total, 1 / (groups * 2.4e6)) + 99e6 + groups * 1.2e6))
+
+
+def test_zero_span_from_raw_rtl_sdr_capture(tmp_path):
+    """`source file:<capture.bin>`: a raw `rtl_sdr` uint8 dump (octave/load_rtlsdr.m:8-12 format) played through
+    the GPU unpack (row A0) -- exercised with both iqFormat values against the oracle."""
+    load_pkg()
+    mod = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.kspecanal")
+    n, frames = 2048, 3
+    full = orc.full_size(n, 2.4e6)
+    x = orc.synth_iq(16 * 1024 + full * frames, 606) * 0.7
+    raw = orc.quantize_u8(x)
+    path = tmp_path / "capture.bin"
+    raw.tofile(path)
+    blocks = orc.unpack_u8(raw[2 * 16 * 1024:]).reshape(frames, full)       # sdr_setup discards 16Ki first (K:301)
+    st, _, _ = orc.zerospan_batch(blocks, n, 0.5, orc.window_table("hamming", n), "MAX", 19.1, 512)
+    for fmt in ("u8", "c64"):
+        mod.sdr_curscan = mod._gpu_curscan
+        d = mod.main(["zeroSpan", "fftSize", str(n), "window", "hamming", "curScanNonOverlap", "0.5",
+                      "curScanCumuMode", "max", "prgLoopCnt", str(frames), "iqFormat", fmt,
+                      "bPltLevels", "false", "bPltHeatMap", "false", "source", "file:%s" % path])
+        for k in ("Cur", "Max", "Min", "Avg"):
+            assert_db(d["Fft." + k], getattr(st, k.lower()), what="%s capture %s" % (fmt, k))
+    # one frame more than the file holds: the loop stops on EOF instead of raising
+    d = mod.main(["zeroSpan", "fftSize", str(n), "window", "hamming", "curScanNonOverlap", "0.5", "prgLoopCnt", "9",
+                  "iqFormat", "u8", "bPltLevels", "false", "bPltHeatMap", "false", "source", "file:%s" % path])
+    assert d["cmd.stop"] is True

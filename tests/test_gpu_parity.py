@@ -288,7 +288,7 @@ def test_adj_siglvls_and_flags(ksa):
 
 
 # ------------------------------------------------------------------------------------------------ scan
-@pytest.mark.parametrize("tag", ["3band_n512", "frac_n256", "quick_n64"])
+@pytest.mark.parametrize("tag", ["3band_n512", "frac_n256", "quick_n64", "baseraw_n256"])
 def test_scan_vs_reference_golden(ksa, torch_cuda, tag):
     torch = torch_cuda
     g = golden("scan_" + tag)
@@ -299,6 +299,7 @@ def test_scan_vs_reference_golden(ksa, torch_cuda, tag):
                              gain=float(g["gain"]), min_amp=float(g["min_amp"]), xres=int(g["xres"]),
                              max_frames=steps, scan_total_entries=groups * n,
                              scan_non_overlap=float(g["scan_non_overlap"]))
+    eng.scan_set_base_is_raw(bool(g["base_is_raw"]))
     x = torch.view_as_real(torch.from_numpy(g["iq"].reshape(passes, steps, full))).cuda()
     for p in range(passes):
         eng.scan_pass_dev(x[p], ksa.FMT_C64, steps)

@@ -60,7 +60,7 @@ def test_zerospan_state_matches_reference(tag):
         assert st.hm_index == frames % 128
 
 
-@pytest.mark.parametrize("tag", ["3band_n512", "frac_n256", "quick_n64"])
+@pytest.mark.parametrize("tag", ["3band_n512", "frac_n256", "quick_n64", "baseraw_n256"])
 def test_scan_state_matches_reference(tag):
     g = golden("scan_" + tag)
     n, full = int(g["fft_size"]), int(g["full"])
@@ -68,7 +68,7 @@ def test_scan_state_matches_reference(tag):
     win = orc.window_table(str(g["window"]), n)
     st = orc.ScanState(n, float(g["start_freq"]), float(g["end_freq"]), float(g["sampling_rate"]),
                        float(g["gain"]), float(g["min_amp"]), int(g["xres"]),
-                       float(g["scan_non_overlap"]))
+                       float(g["scan_non_overlap"]), base_is_raw=bool(g["base_is_raw"]))
     assert len(st.centers) == steps
     x = g["iq"].reshape(passes, steps, full)
     for p in range(passes):
