@@ -190,12 +190,16 @@ struct Tune {
   static constexpr bool WIN_GLOBAL = Plan<N>::T >= 512;
 #endif
   static constexpr int LDS_BYTES = Plan<N>::LDS_BYTES + (WIN_LDS ? N * 4 : 0);
-  // prefetch only on the general path: with sample reuse the carried half plus a prefetched half spill
+  // Next-window prefetch into a second VGPR set: measured OFF everywhere.  With the fused radix-16 the extra
+  // 16-32 registers push hipcc into spills (N=4096 at the default 0.1 hop: 104 -> 165 M FFT/s without it;
+  // with sample reuse 2.5 ms -> 1.6 ms).  Kept behind -DKSA_PREFETCH=1 for re-measurement.
   static constexpr bool pf(int rm) {
 #ifdef KSA_PREFETCH
+    (void)rm;
     return KSA_PREFETCH;
 #else
-    return Plan<N>::T < 512 && rm == 0;
+    (void)rm;
+    return false;
 #endif
   }
 };
