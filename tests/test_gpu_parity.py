@@ -411,3 +411,49 @@ def test_rccl_merge_path_single_rank(ksa, torch_cuda):
             assert np.array_equal(a[k], b[k]), k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,xres", [(128, 64), (64, 64), (1024, 512), (4096, 16), (16384, 32), (16384, 8192), (256, 4), (65536, 64)])
+def test_waterfall_cell_paths(ksa, torch_cuda, n, xres):
+    """Every waterfall reduction path of the output stage: g = N/W of 1, 2, 4..256 (shuffles) and > 256 (LDS),
+    on the single-workgroup and the four-step kernels."""
+    torch = torch_cuda
+    full, frames = 2 * n, 3
+    x = orc.synth_iq(full * frames, 900 + n + xres).astype(np.complex64).reshape(frames, full)
+    st_ref, db_ref, _ = orc.zerospan_batch(x, n, 0.5, orc.window_table("hamming", n), "AVG", GAIN, xres)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hamming", gain=GAIN, xres=xres, max_frames=frames)
+    assert eng.hm_width == min(n, xres)
+    rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
+    eng.frames_dev(torch.view_as_real(torch.from_numpy(x)).cuda(), ksa.FMT_C64, frames, hm_rows=rows)
+    st = eng.state()
+    assert_db(rows.cpu().numpy(), st_ref.hm[:frames], what="rows N=%d W=%d" % (n, xres))
+    assert_db(st["fftHM"][:frames], st_ref.hm[:frames], what="ring N=%d W=%d" % (n, xres))
+    eng.close()
+
+
+def test_frame_stride_and_batch_limits(ksa, torch_cuda):
+    """Frames may overlap or be spaced in the device buffer (frame_stride != fullSize); batches beyond
+    max_frames, misaligned outputs and empty batches are refused."""
+    torch = torch_cuda
+    n, full = 1024, 8192
+    x = orc.synth_iq(full * 6, 321).astype(np.complex64)
+    dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+    win = orc.window_table("hanning", n)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", max_frames=8)
+    for stride, frames in ((full // 2, 8), (full + 1024, 4), (3, 5)):
+        out = torch.empty((frames, n), dtype=torch.float32, device="cuda")
+        eng.curscan_dev(dev, ksa.FMT_C64, frames, out, frame_stride=stride)
+        want = np.array([orc.curscan(x[f * stride:f * stride + full], n, 0.5, win, "AVG") for f in range(frames)])
+        assert_lin(out.cpu().numpy(), want, what="stride %d" % stride)
+    out = torch.empty((9, n), dtype=torch.float32, device="cuda")
+    with pytest.raises(ksa.KsaError):
+        eng.curscan_dev(dev, ksa.FMT_C64, 9, out)                      # > max_frames
+    with pytest.raises(ksa.KsaError):
+        eng.curscan_dev(dev, ksa.FMT_C64, 0, out)                      # empty batch
+    with pytest.raises(ksa.KsaError):
+        eng.curscan_dev(dev, ksa.FMT_C64, 2, out.view(-1)[1:])         # output not 16-byte aligned
+    with pytest.raises(ksa.KsaError):
+        eng.frames_dev(dev, ksa.FMT_C64, 4, first_index=6, total_frames=8)   # batch runs past the run
+    with pytest.raises(ksa.KsaError):
+        eng.commit(4)                                                  # nothing pending
+    eng.close()
