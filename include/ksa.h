@@ -96,9 +96,9 @@ int ksa_frame_c64(ksa_engine* e, const float* iq_host);
 int ksa_frame_u8(ksa_engine* e, const uint8_t* iq_host);
 /* zeroSpanPlay (K:547-564 feeding K:469-484): accumulate an already computed linear spectrum. */
 int ksa_frame_spectrum(ksa_engine* e, const float* mag_host /* [fft_size], fftshifted */);
-/* Partial block of the last ksa_frames_dev(commit=0): float[4][N] = {max, cur-or--inf, min, sum}
- * on the device -- all-reduce rows 0-1 with MAX, row 2 with MIN, row 3 with SUM across the ranks
- * that share a run, then ksa_commit on every rank. */
+/* Partial block of the last ksa_frames_dev(commit=0): float[4][N] = {max, cur-or--inf, -min, sum}
+ * on the device -- all-reduce rows 0-2 with MAX (the minimum travels negated) and row 3 with SUM across
+ * the ranks that share a run, then ksa_commit on every rank. */
 int ksa_partial_dev(ksa_engine* e, float** partial_dev);
 int ksa_commit(ksa_engine* e, int64_t total_frames);
 /* GUI toggles bDataMax/bDataMin/bDataAvg (K:71-73, K:471-476) */

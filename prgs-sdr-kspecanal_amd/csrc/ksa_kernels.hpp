@@ -539,7 +539,7 @@ __global__ void accumulate_partial_kernel(const AccParams p) {
   o[2 * stride4] = make_float4(sum[0], sum[1], sum[2], sum[3]);
 }
 
-// partial block layout: [max | cur-or--inf | min | sum], N floats each.
+// partial block layout: [max | cur-or--inf | -min | sum], N floats each.
 // Workgroup = 64 bins x 16 chunk groups (1024 threads): every thread folds chunks/16 partials, the 16
 // groups are combined through LDS in chunk order, so the short dependent chains run in parallel.
 __global__ __launch_bounds__(1024) void accumulate_reduce_kernel(const float* part, int chunks, int n, const float* last_db,
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(1024) void accumulate_reduce_kernel(const float* pa
     }
     partial[bin] = mx;
     partial[n + bin] = owns_last ? last_db[bin] : -__builtin_inff();
-    partial[2 * n + bin] = mn;
+    partial[2 * n + bin] = -mn;   // negated: one MAX all-reduce then covers max | cur | -min
     partial[3 * n + bin] = sum;
   }
 }
@@ -580,7 +580,7 @@ __global__ void commit_kernel(const float* partial, float* state, int n, int has
                               long long total_frames, int b_max, int b_min, int b_avg) {
   const int bin = blockIdx.x * blockDim.x + threadIdx.x;
   if (bin >= n) return;
-  const float mx = partial[bin], cur = partial[n + bin], mn = partial[2 * n + bin], sum = partial[3 * n + bin];
+  const float mx = partial[bin], cur = partial[n + bin], mn = -partial[2 * n + bin], sum = partial[3 * n + bin];
   state[bin] = cur;
   if (b_max) state[n + bin] = has_prev ? nan_max(state[n + bin], mx) : mx;
   if (b_min) state[2 * n + bin] = has_prev ? nan_min(state[2 * n + bin], mn) : mn;

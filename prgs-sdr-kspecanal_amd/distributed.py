@@ -4,7 +4,7 @@ The reference's frame loop (python/kspecanal.py:460-484) is sequential only thro
 Frames are independent up to the dB spectrum, so rank r takes frames [r*F, (r+1)*F) of a run of
 G*F frames and the accumulators are merged with the algebra of SURVEY.md 8(e):
 
-  Max, Min  -> elementwise all-reduce MAX / MIN
+  Max, Min  -> elementwise all-reduce MAX (Min travels negated in the same buffer)
   Avg       -> the (a+x)/2 recursion (K:137-139) in closed form is sum_k 2^-(n-k+1) x_k; every rank sums
                its frames with their GLOBAL weights (libksa does that given first_index/total_frames), then
                one all-reduce SUM
@@ -13,7 +13,8 @@ G*F frames and the accumulators are merged with the algebra of SURVEY.md 8(e):
                correct ring slots, one all-gather picks each slot from the rank that owns its newest frame.
 
 Message sizes are a few KiB..MiB (latency bound on xGMI), so the collectives are fused: one MAX over
-[max|cur], one MIN, one SUM, one all-gather -- per batch, not per frame.
+[max|cur|-min], one SUM, and one broadcast (or all-gather when a rank holds < 128 frames) for the ring --
+per batch, not per frame.
 The tensor algebra below is device agnostic (tested on CPU with gloo, run on GPUs with nccl = RCCL).
 """
 import torch
@@ -23,9 +24,9 @@ HM_ROWS = 128
 
 
 def merge_partials(partial, group=None):
-    """partial: float32[4, N] = {max, cur-or--inf, min, weighted sum} of this rank's chunk, in place."""
-    dist.all_reduce(partial[0:2], op=dist.ReduceOp.MAX, group=group)
-    dist.all_reduce(partial[2], op=dist.ReduceOp.MIN, group=group)
+    """partial: float32[4, N] = {max, cur-or--inf, -min, weighted sum} of this rank's chunk, in place.
+    The minimum travels negated so that ONE MAX all-reduce covers three rows; one SUM covers the fourth."""
+    dist.all_reduce(partial[0:3], op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(partial[3], op=dist.ReduceOp.SUM, group=group)
     return partial
 
@@ -45,6 +46,9 @@ def ring_owner(idx0, frames_per_rank, world):
 
 def merge_ring(ring, idx0, frames_per_rank, world, group=None):
     """ring: float32[128, W] of this rank (rows written at globally correct slots), merged in place."""
+    if frames_per_rank >= HM_ROWS:
+        dist.broadcast(ring, src=world - 1, group=group)   # the last 128 frames all live on the last rank
+        return ring
     gathered = [torch.empty_like(ring) for _ in range(world)]
     dist.all_gather(gathered, ring.contiguous(), group=group)
     owner = ring_owner(idx0, frames_per_rank, world).to(ring.device)

@@ -199,7 +199,7 @@ class SpectrumEngine:
                                  _ptr(cur_db), _ptr(hm_rows), 1 if commit else 0))
 
     def partial(self):
-        """Device view float32[4, N] = {max, cur-or--inf, min, weighted sum} of the uncommitted batch."""
+        """Device view float32[4, N] = {max, cur-or--inf, -min, weighted sum} of the uncommitted batch."""
         p = C.c_void_p()
         check(lib.ksa_partial_dev(self._h, C.byref(p)))
         return DevArray(p.value, (4, self.fft_size), self)

@@ -19,7 +19,7 @@ N, FULL, Q, GAIN, XRES = 256, 2048, 0.5, 19.1, 64
 
 
 def _partial_from_oracle(db, first_index, total, has_prev, owns_last):
-    """[max, cur-or--inf, min, sum_k 2^-(n-k+1) x_k] -- what accumulate_partial/reduce leave on a rank."""
+    """[max, cur-or--inf, -min, sum_k 2^-(n-k+1) x_k] -- what accumulate_partial/reduce leave on a rank."""
     f, n = db.shape
     w = np.empty(f)
     for i in range(f):
@@ -31,7 +31,7 @@ def _partial_from_oracle(db, first_index, total, has_prev, owns_last):
     part = np.empty((4, n), dtype=np.float32)
     part[0] = db.max(axis=0)
     part[1] = db[-1] if owns_last else -np.inf
-    part[2] = db.min(axis=0)
+    part[2] = -db.min(axis=0)
     part[3] = (w[:, None] * db).sum(axis=0)
     return part
 
@@ -82,7 +82,7 @@ def test_two_rank_merge_equals_sequential_run(tmp_path, frames_per_rank, idx0):
     st, db, _ = orc.zerospan_batch(x, N, Q, orc.window_table("hanning", N), "AVG", GAIN, XRES)
     assert np.allclose(got["part"][0], st.max, rtol=0, atol=1e-4)
     assert np.allclose(got["part"][1], st.cur, rtol=0, atol=1e-4)
-    assert np.allclose(got["part"][2], st.min, rtol=0, atol=1e-4)
+    assert np.allclose(-got["part"][2], st.min, rtol=0, atol=1e-4)
     assert np.allclose(got["part"][3], st.avg, rtol=0, atol=1e-3)     # float32 transport of a float64 EMA
     # waterfall ring: the oracle's ring starts at index 0; rotate to the run's starting slot
     want = np.full((128, XRES), 7.0)
