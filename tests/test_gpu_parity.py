@@ -457,3 +457,56 @@ def test_frame_stride_and_batch_limits(ksa, torch_cuda):
     with pytest.raises(ksa.KsaError):
         eng.commit(4)                                                  # nothing pending
     eng.close()
+
+
+@pytest.mark.parametrize("frames_per_rank,ranks", [(40, 2), (200, 3), (5, 4)])
+def test_time_chunk_shards_equal_one_run(ksa, torch_cuda, frames_per_rank, ranks):
+    """SURVEY 8(e) on the device: `ranks` engines each process their time chunk with the run's global frame
+    indices (ksa_frames_dev first_index/total_frames, commit = 0), the partial blocks are merged with the MAX /
+    SUM algebra the RCCL path uses, every engine commits -- and all of them must equal one engine that saw the
+    whole run in order (and the float64 oracle)."""
+    torch = torch_cuda
+    dmod = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
+    n, full = 512, 4096
+    total = frames_per_rank * ranks
+    x = orc.synth_iq(full * total, 1234 + total).astype(np.complex64).reshape(total, full)
+    dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+    mk = lambda: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=128,
+                                    max_frames=total)
+    one = mk()
+    one.frames_dev(dev[:7], ksa.FMT_C64, 7)          # some history first, so that has_prev is exercised
+    one.frames_dev(dev, ksa.FMT_C64, total)
+    want = one.state()
+    engines = [mk() for _ in range(ranks)]
+    parts = []
+    for r, eng in enumerate(engines):
+        eng.frames_dev(dev[:7], ksa.FMT_C64, 7)
+        eng.set_hm_index((7 + r * frames_per_rank) % 128)
+        eng.frames_dev(dev[r * frames_per_rank:(r + 1) * frames_per_rank], ksa.FMT_C64, frames_per_rank,
+                       first_index=r * frames_per_rank, total_frames=total, commit=False)
+        parts.append(torch.as_tensor(eng.partial(), device="cuda"))
+    merged = torch.stack(parts)
+    mx = merged[:, 0:3].max(dim=0).values            # what all_reduce(MAX) leaves on every rank
+    sm = merged[:, 3].sum(dim=0)                     # all_reduce(SUM)
+    rings = []
+    for eng, p in zip(engines, parts):
+        p[0:3] = mx
+        p[3] = sm
+        eng.commit(total)
+        rings.append(torch.as_tensor(eng.state_dev()[1], device="cuda").clone())
+    own = dmod.ring_owner(7, frames_per_rank, ranks)
+    for eng in engines:
+        st = eng.state()
+        assert st["frames"] == want["frames"] == 7 + total
+        for k in ("Fft.Cur", "Fft.Max", "Fft.Min"):
+            assert np.array_equal(st[k], want[k]), k
+        assert np.max(np.abs(st["Fft.Avg"] - want["Fft.Avg"])) < 2e-5      # same terms, different summation order
+    ring = want["fftHM"]
+    for slot in range(128):
+        if own[slot] >= 0:
+            assert np.array_equal(rings[int(own[slot])][slot].cpu().numpy().astype(np.float64), ring[slot]), slot
+    ref, _, _ = orc.zerospan_batch(np.concatenate([x[:7], x]), n, 0.5, orc.window_table("hanning", n), "AVG", GAIN, 128)
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(want["Fft." + k.capitalize()], getattr(ref, k), what="one-run " + k)
+    for eng in engines + [one]:
+        eng.close()
