@@ -1,6 +1,6 @@
 #!/bin/bash
 # run on the GPU box: bench every variants/libksa_*.so given as args, print kernel ms
-cd "$(dirname "$0")"
+cd "$(dirname "$0")/.."
 for v in "$@"; do
   KSA_LIB=$PWD/variants/libksa_$v.so timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
 import sys,json

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B on the GPU box: sweep2.sh "<ENV=val ...>:<variant>" ...   e.g. "KSA_NO_REUSE=1:rm"
-cd "$(dirname "$0")"
+cd "$(dirname "$0")/.."
 for spec in "$@"; do
   envs=${spec%%:*}; v=${spec#*:}
   env $envs KSA_LIB=$PWD/variants/libksa_$v.so timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
