@@ -128,6 +128,11 @@ int ksa_scan_reset(ksa_engine* e);
  * [iStart:iEnd] instead of the stitched Fft.Cur over [iStart:iDone]. */
 int ksa_scan_set_base_is_raw(ksa_engine* e, int32_t on);
 
+/* ---- plot-side decimation (data_plotcompress / _data_plotcompress, K:168-221) ------------------------------- */
+/* The four curves (cur, max, min, avg; minus Fft.Adj if set, K:400-411) reduced on the device to `cells`
+ * groups with pltCompress AVG (0) / MAX (1) / MIN (2): out_host[4][cells].  scan != 0 reads the scan state. */
+int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, float* out_host);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event timing of the spectrum kernel on the engine's stream: enable, run, then read the sum
  * of kernel durations and the launch count since the last enable. */

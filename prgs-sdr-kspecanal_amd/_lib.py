@@ -63,6 +63,7 @@ SIGNATURES = {
     "ksa_scan_state_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "ksa_scan_reset": (C.c_int, [_P]),
     "ksa_scan_set_base_is_raw": (C.c_int, [_P, _I32]),
+    "ksa_read_levels": (C.c_int, [_P, _I32, _I32, _I32, _P]),
     "ksa_prof_enable": (C.c_int, [_P, _I32]),
     "ksa_prof_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "ksa_kernel_info": (C.c_int, [_P] + [C.POINTER(_I32)] * 5),

@@ -78,6 +78,8 @@ struct ksa_engine {
   float* d_hm = nullptr;        // [128][hm_width]
   float* d_scan_state = nullptr;  // [4][total]
   float* d_scan_hm = nullptr;     // [128][scan_hm_width]
+  float* d_levels = nullptr;      // [4][cells] plot-side decimation scratch
+  int levels_cap = 0;
   ksa::FourStep four;           // N > 16384
   // bookkeeping
   long long frames_seen = 0;
@@ -455,7 +457,8 @@ void ksa_destroy(ksa_engine* e) {
   hipDeviceSynchronize();
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   void* ptrs[] = {e->d_starts, e->d_start_last, e->d_window, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
-                  e->d_iq_stage, e->d_frames, e->d_part, e->d_partial, e->d_state, e->d_hm, e->d_scan_state, e->d_scan_hm};
+                  e->d_iq_stage, e->d_frames, e->d_part, e->d_partial, e->d_state, e->d_hm, e->d_scan_state, e->d_scan_hm,
+                  e->d_levels};
   for (void* p : ptrs) if (p) hipFree(p);
   ksa::fourstep_destroy(e->four);
   delete e;
@@ -705,6 +708,28 @@ int ksa_scan_reset(ksa_engine* e) {
   if (!e) return fail("null engine");
   HIP_OK(hipSetDevice(e->cfg.device));
   return scan_reset(e);
+}
+
+int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, float* out_host) {
+  if (!e || !out_host) return fail("null argument");
+  if (mode < 0 || mode > 2) return fail("levels mode %d (0 AVG, 1 MAX, 2 MIN)", mode);
+  const int n = scan ? e->cfg.scan_total_entries : e->cfg.fft_size;
+  if (scan && !n) return fail("engine was created without scan geometry");
+  if (cells < 1 || n % cells) return fail("cells %d must divide %d", cells, n);
+  HIP_OK(hipSetDevice(e->cfg.device));
+  if (!e->d_levels || e->levels_cap < cells) {
+    if (e->d_levels) hipFree(e->d_levels);
+    e->d_levels = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_levels), (size_t)4 * cells * 4));
+    e->levels_cap = cells;
+  }
+  const int tb = 128;
+  hipLaunchKernelGGL(ksa::levels_kernel, dim3((cells + tb - 1) / tb, 4), dim3(tb), 0, e->stream,
+                     scan ? e->d_scan_state : e->d_state, scan ? e->d_scan_adj : e->d_adj, n, cells, mode, e->d_levels);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(out_host, e->d_levels, (size_t)4 * cells * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  return 0;
 }
 
 int ksa_prof_enable(ksa_engine* e, int32_t on) {

@@ -639,6 +639,31 @@ __global__ void scan_stitch_kernel(const StitchParams p) {
   }
 }
 
+// Plot-side decimation on the device (data_plotcompress / _data_plotcompress, K:168-221): curve c of `src`
+// ([ncurves][n]) is cut into `cells` groups of g = n/cells bins and reduced with AVG / MAX / MIN, minus the
+// optional Fft.Adj baseline (K:400-411), so only cells-sized arrays cross PCIe for the Levels plot.
+// mode: 0 AVG, 1 MAX, 2 MIN.  blockIdx.y = curve.
+__global__ void levels_kernel(const float* src, const float* adj, int n, int cells, int mode, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cells) return;
+  const int g = n / cells;
+  const float* row = src + (long long)blockIdx.y * n + (long long)c * g;
+  const float* arow = adj ? adj + (long long)c * g : nullptr;
+  float acc = mode == 0 ? 0.f : (mode == 1 ? -__builtin_inff() : __builtin_inff());
+  double sum = 0.0;   // np.average accumulates in float64 (pairwise); float64 here keeps the order irrelevant
+  bool nan = false;
+  for (int i = 0; i < g; ++i) {
+    float v = row[i];
+    if (arow) v -= arow[i];
+    nan |= v != v;
+    if (mode == 0) sum += (double)v;
+    else if (mode == 1) acc = fmaxf(acc, v);
+    else acc = fminf(acc, v);
+  }
+  if (mode == 0) acc = (float)(sum / (double)g);
+  out[(long long)blockIdx.y * cells + c] = nan ? __builtin_nanf("") : acc;
+}
+
 __global__ void fill_kernel(float* dst, long long n, float v) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = v;
 }

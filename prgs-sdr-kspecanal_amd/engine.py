@@ -269,6 +269,14 @@ class SpectrumEngine:
     def scan_set_base_is_raw(self, on):
         check(lib.ksa_scan_set_base_is_raw(self._h, int(bool(on))))
 
+    def levels(self, cells, mode="AVG", scan=False):
+        """Cur/Max/Min/Avg decimated on the device to `cells` points (pltCompress AVG|MAX|MIN, K:205-221),
+        baseline-adjusted like _adj_siglvls (K:400-411): float64[4, cells] in the order cur, max, min, avg."""
+        code = {"AVG": 0, "MAX": 1, "MIN": 2}[mode.upper()]
+        out = np.empty((4, int(cells)), dtype=np.float32)
+        check(lib.ksa_read_levels(self._h, int(bool(scan)), code, int(cells), _ptr(out)))
+        return out.astype(np.float64)
+
     # -- measurement ------------------------------------------------------------------------------------
     def prof_enable(self, on=True):
         check(lib.ksa_prof_enable(self._h, int(on)))

@@ -365,8 +365,28 @@ def plot_highs(d, freqs, levels):
     return marked
 
 
-def _plot_levels(d, freqs, cur):
+def _plot_levels(d, freqs, cur, eng=None, scan=False):
+    """Levels hand-off (K:485-504 / K:670-688).  With pltCompress AVG|MAX|MIN the four curves are decimated to
+    xRes points on the device (ksa_read_levels) and only those cross PCIe; RAW / CONV use the full arrays."""
     fmax, fmin, favg, fcur = _adj_siglvls(d, cur)
+    mode = d["pltCompress"]
+    if eng is not None and mode in ("AVG", "MAX", "MIN") and len(freqs) // d["xRes"] > 0 and len(freqs) % d["xRes"] == 0:
+        lv = eng.levels(d["xRes"], mode, scan=scan)               # rows: cur, max, min, avg (baseline-adjusted)
+        xs = _plotcompress(d, freqs, "AVG")
+        curves = (("bDataMax", lv[1], "r"), ("bDataMin", lv[2], "y"), ("bDataAvg", lv[3], "g"), ("bDataCur", lv[0], "b"))
+        x = y = None
+        if d.get("plt") is not None and d["bPltLevels"]:
+            d["AxLevels"].cla()
+            if d["bGrid"]:
+                d["AxLevels"].grid(True)
+        for flag, data, colour in curves:
+            if d[flag]:
+                x, y = xs, data
+                if d.get("plt") is not None and d["bPltLevels"]:
+                    d["AxLevels"].plot(x, y, colour)
+        if x is not None:
+            plot_highs(d, x, y)
+        return
     x = y = None
     curves = (("bDataMax", fmax, "r"), ("bDataMin", fmin, "y"), ("bDataAvg", favg, "g"), ("bDataCur", fcur, "b"))
     if d.get("plt") is not None and d["bPltLevels"]:
@@ -437,7 +457,7 @@ def zero_span(d):
             d["Fft.Avg"] = None
         d["fftHM"], d["fftHMIndex"] = st["fftHM"], st["hm_index"]
         _plot_heatmap(d, d["fftHM"])
-        _plot_levels(d, freqs, d["Fft.Cur"])
+        _plot_levels(d, freqs, d["Fft.Cur"], eng)
 
 
 def zero_span_save(d):
@@ -540,7 +560,7 @@ def scan_range(d):
         for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg"):
             d[k] = st[k]
         d["fftHM"], d["fftHMIndex"] = st["fftHM"], st["hm_index"]
-        _plot_levels(d, d["freqsAll"], d["Fft.Cur"])
+        _plot_levels(d, d["freqsAll"], d["Fft.Cur"], eng, scan=True)
         _plot_heatmap(d, d["fftHM"])
 
 

@@ -510,3 +510,26 @@ def test_time_chunk_shards_equal_one_run(ksa, torch_cuda, frames_per_rank, ranks
         assert_db(want["Fft." + k.capitalize()], getattr(ref, k), what="one-run " + k)
     for eng in engines + [one]:
         eng.close()
+
+
+def test_device_levels_decimation(ksa):
+    """data_plotcompress on the device (K:205-221, with the Fft.Adj baseline of K:400-411) vs the oracle's
+    _data_plotcompress restatement on the full-size curves."""
+    n, full = 2048, 16384
+    x = orc.synth_iq(full * 4, 2468).astype(np.complex64).reshape(4, full)
+    adj = np.sin(np.arange(n) / 50.0)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=256)
+    eng.set_adj(adj)
+    for fr in x:
+        eng.frame(fr)
+    st = eng.state()
+    for mode in ("AVG", "MAX"):
+        got = eng.levels(256, mode)
+        for row, key in enumerate(("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg")):
+            want = orc.plotcompress(st[key] - adj, 256, mode)
+            assert np.max(np.abs(got[row] - want)) < 2e-5, (mode, key)
+    got = eng.levels(256, "MIN")
+    assert np.max(np.abs(got[0] - (st["Fft.Cur"] - adj).reshape(256, -1).min(axis=1))) < 2e-5
+    with pytest.raises(ksa.KsaError):
+        eng.levels(300)
+    eng.close()
