@@ -108,12 +108,14 @@ template <int N, int FMT, int RM>
 int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
   using P = ksa::Plan<N>;
   auto kfn = ksa::spectrum_kernel<N, FMT, RM>;
+  static const int lds_pad = getenv("KSA_LDS_PAD_KB") ? atoi(getenv("KSA_LDS_PAD_KB")) * 1024 : 0;   // occupancy experiments
+  const int lds_bytes = ksa::Tune<N>::LDS_BYTES + lds_pad;
   if (configure_only) {
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, ksa::Tune<N>::LDS_BYTES));
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipFuncAttributes attr;
     HIP_OK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kfn)));
     int occ = 0;
-    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, P::T, ksa::Tune<N>::LDS_BYTES));
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, P::T, lds_bytes));
     if (FMT == ksa::FMT_C64) {
       e->threads = P::T;
       e->lds_bytes = ksa::Tune<N>::LDS_BYTES;
@@ -128,7 +130,7 @@ int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
   const long long sb = FMT == ksa::FMT_C64 ? 8 : 2;
   const long long room = ((1ll << 31) - 1) / sb - p.frame_len;
   if (p.frame_stride > 0 && (long long)grid * p.frame_stride > room) grid = (int)std::max<long long>(1, room / p.frame_stride);
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), ksa::Tune<N>::LDS_BYTES, e->stream, p);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), lds_bytes, e->stream, p);
   HIP_OK(hipGetLastError());
   return 0;
 }
