@@ -77,9 +77,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
+    # one rank per GPU; KSA_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the launch path
+    backend = os.environ.get("KSA_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     frames = args.frames
     sb = 8 if args.fmt == "c64" else 2
@@ -146,7 +152,7 @@ def main():
             "config": {"workload": "configs[1]: zeroSpan synthetic 2.4 MS/s IQ, fftSize=4096, 50% overlap, hanning",
                        "input": "complex64" if args.fmt == "c64" else "uint8", "frames_per_gpu_per_step": frames,
                        "samples_per_frame": FULL, "windows_per_frame": nwin, "sharding": "time-chunk",
-                       "collective": "RCCL all-reduce x3 per step" if world > 1 else "none"},
+                       "collective": "RCCL: 1 MAX + 1 SUM all-reduce of [N] curves + 1 ring broadcast per step" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ksa::spectrum_kernel<4096,%s>" % ("c64" if args.fmt == "c64" else "u8"),
