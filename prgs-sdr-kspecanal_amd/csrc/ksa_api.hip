@@ -124,12 +124,7 @@ int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
     }
     return 0;
   }
-  int grid = std::max(1, std::min(p.nframes, e->num_cu * e->blocks_per_cu));
-  // the prefetch path addresses the next frame (frame + grid) through the current frame's 32-bit
-  // buffer offsets: keep (grid*stride + fullSize) * sample_bytes below 2^31
-  const long long sb = FMT == ksa::FMT_C64 ? 8 : 2;
-  const long long room = ((1ll << 31) - 1) / sb - p.frame_len;
-  if (p.frame_stride > 0 && (long long)grid * p.frame_stride > room) grid = (int)std::max<long long>(1, room / p.frame_stride);
+  const int grid = std::max(1, std::min(p.nframes, e->num_cu * e->blocks_per_cu));
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), lds_bytes, e->stream, p);
   HIP_OK(hipGetLastError());
   return 0;

@@ -190,18 +190,6 @@ struct Tune {
   static constexpr bool WIN_GLOBAL = Plan<N>::T >= 512;
 #endif
   static constexpr int LDS_BYTES = Plan<N>::LDS_BYTES + (WIN_LDS ? N * 4 : 0);
-  // Next-window prefetch into a second VGPR set: measured OFF everywhere.  With the fused radix-16 the extra
-  // 16-32 registers push hipcc into spills (N=4096 at the default 0.1 hop: 104 -> 165 M FFT/s without it;
-  // with sample reuse 2.5 ms -> 1.6 ms).  Kept behind -DKSA_PREFETCH=1 for re-measurement.
-  static constexpr bool pf(int rm) {
-#ifdef KSA_PREFETCH
-    (void)rm;
-    return KSA_PREFETCH;
-#else
-    (void)rm;
-    return false;
-#endif
-  }
 };
 
 // RM > 0: consecutive windows are exactly RM*L samples apart (L = N/16 threads), so thread l's samples
@@ -258,25 +246,20 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   const int rounds = (p.nwin + S - 1) / S;
   const int nm1 = p.nwin - 1;
 
-  // Raw IQ of one window per thread: 16 samples l + L*q.  The loads for the NEXT window are issued
-  // right after the current one has been consumed, so their HBM/L2 latency runs under the two
-  // remaining passes (plain VMEM loads stay in flight across s_barrier).
+  // Raw IQ of one window per thread: 16 samples l + L*q, loaded at the top of the window (8 B/lane, 512 B per
+  // wave-instruction).  The buffer descriptor is built from scalars only (a per-lane descriptor makes hipcc wrap
+  // every load in a readfirstlane "waterfall" loop) and spans exactly this frame: every load is range-checked
+  // by the hardware.  Prefetching the next window into a second register set was measured and dropped
+  // (spills: 104 -> 165 M FFT/s without it at the 0.1 hop; 2.5 -> 1.6 ms with sample reuse).
   typedef typename std::conditional<FMT == FMT_C64, u32x2, unsigned short>::type raw_t;
   raw_t raw[16];
   const int start0 = p.starts[0];
-  // Loads of window k of frame `fr`, addressed relative to the wave-uniform frame `base_fr` so that the
-  // buffer descriptor is built from scalars only (a per-lane descriptor makes hipcc wrap every load in
-  // a readfirstlane "waterfall" loop).  The descriptor spans base_fr .. base_fr + gridDim.x frames
-  // (clipped to the batch), every load is range-checked by the hardware.
-  auto issue_loads = [&](int base_fr, int fr, int k, int q0) {
-    const char* fbase = reinterpret_cast<const char*>(p.iq) + (long long)base_fr * p.frame_stride * SB;
-    int span = p.nframes - 1 - base_fr;
-    if (span > (int)gridDim.x) span = gridDim.x;
-    const long long bytes = ((long long)span * p.frame_stride + p.frame_len) * SB;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fbase), 0, (int)bytes, 0x00020000);
+  auto issue_loads = [&](int fr, int k, int q0) {
+    const char* fbase = reinterpret_cast<const char*>(p.iq) + (long long)fr * p.frame_stride * SB;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fbase), 0, p.frame_len * SB, 0x00020000);
     // reuse path: hops are constant (RM*L samples), so the start is arithmetic -- no dependent scalar load
     const int start = RM > 0 ? start0 + k * (RM * L) : p.starts[k];
-    const int voff = ((fr - base_fr) * (int)p.frame_stride + start + l) * SB;
+    const int voff = (start + l) * SB;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       if (q < q0) continue;
@@ -293,8 +276,6 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
 #pragma unroll
     for (int q = 0; q + RM < 16; ++q) raw[q] = raw[q + RM];
   };
-  constexpr bool PF = Tune<N>::pf(RM);
-  if (PF && (int)blockIdx.x < p.nframes && slot < p.nwin) issue_loads(blockIdx.x, blockIdx.x, slot, 0);
 
 #ifdef KSA_STAMPS
   unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -311,7 +292,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       const int k = S == 1 ? rd : rd * S + slot;   // wave-uniform when one transform fills the workgroup
       const bool active = S == 1 || k < p.nwin;
       float2 v[16];
-      if (!PF && active) issue_loads(frame, frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
+      if (active) issue_loads(frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
       if (active) {
         if constexpr (!WIN_LDS && Tune<N>::WIN_GLOBAL) {
           // scalar descriptor + scalar offsets: no per-load address VGPRs
@@ -340,18 +321,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
           }
         }
       }
-      if (PF) {
-        int nk = k + S, nf = frame;
-        if (nk >= p.nwin) { nk = slot; nf = frame + gridDim.x; }
-        if (nf < p.nframes && nk < p.nwin) {
-          if (RM > 0 && nf == frame) {
-            shift_raw();
-            issue_loads(frame, nf, nk, 16 - RM);
-          } else {
-            issue_loads(frame, nf, nk, 0);
-          }
-        }
-      } else if (RM > 0) {
+      if (RM > 0) {
         shift_raw();   // the next round of this frame loads only its RM new samples
       }
       KSA_STAMP(0);
