@@ -150,11 +150,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define KSA_LDS_LD(dst, src) (dst) = (src)
 #endif
 
-// Per-size launch tuning (measured on MI355X): waves per SIMD the register allocator must
-// leave room for, and whether the next window's IQ is prefetched into VGPRs.  LDS caps a CU at four
-// 4096-point transforms in flight whatever the register count, and the kernel is VALU-issue bound, so
-// for T <= 256 three spill-free waves with prefetch beat four spilling ones; 1024-thread workgroups
-// need 4 waves per SIMD by construction.
+// Per-size tuning, every choice measured A/B on MI355X.  WPS = waves per SIMD the
+// register allocator must leave room for: LDS caps a CU at three to four 4096-point transforms in flight
+// whatever the register count, so for T <= 256 three spill-free waves (168 VGPRs) beat four spilling ones;
+// 1024-thread workgroups need 4 waves per SIMD (128 VGPRs) by construction.  The -D overrides exist for
+// tools/variants.sh experiments only.
 template <int N>
 struct Tune {
 #ifdef KSA_WAVES_PER_SIMD
