@@ -56,6 +56,47 @@ def cpu_baseline(seconds=12.0):
                       % (done, done * nwin, dt, len(os.sched_getaffinity(0)))}
 
 
+def _cpu_worker(args):
+    seconds, seed = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ksa_oracle as orc
+    win = orc.window_table(WINDOW, N_FFT)
+    x = orc.synth_iq(FULL * 16, seed).astype(np.complex64).reshape(16, FULL)
+    st = orc.ZeroSpanState(N_FFT, XRES, GAIN)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for fr in x:
+            st.push(orc.curscan(fr, N_FFT, Q, win, "AVG"))
+        done += 16
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline_multicore(seconds=6.0, max_workers=16):
+    """the same numpy port on independent frames, one plain child process per usable core (capped
+    at the box's CPU share) -- the non-target multi-core figure.  Children never touch the GPU; any failure or
+    timeout just drops the figure."""
+    import subprocess
+    workers = max(1, min(max_workers, len(os.sched_getaffinity(0))))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds), str(100 + i)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(workers)]
+    res = []
+    try:
+        for pr in procs:
+            out, _ = pr.communicate(timeout=seconds + 60)
+            done, dt = out.strip().split()[-2:]
+            res.append((int(done), float(dt)))
+    except Exception:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        return None
+    frames = sum(r[0] for r in res)
+    dt = max(r[1] for r in res)
+    return {"value": frames * 15 / dt, "unit": "FFT/s", "cores": workers, "kind": "port",
+            "sample": "%d frames over %d processes in %.1f s, numpy float64" % (frames, workers, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +212,9 @@ def main():
                 pass
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            multi = cpu_baseline_multicore()
+            if multi is not None:
+                out["cpu_baseline_multicore"] = multi
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -178,4 +222,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-worker":     # child of cpu_baseline_multicore
+        print(*_cpu_worker((float(sys.argv[2]), int(sys.argv[3]))))
+    else:
+        main()
