@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Host-pointer entry points (the literal drop-in path): frames per second of ksa_frame_c64 / ksa_curscan_c64 /
+ksa_frame_u8 including the H2D copy, launches and the synchronise, one block per call."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ksa_oracle as orc
+ksa = importlib.import_module("prgs-sdr-kspecanal_amd")
+for n, q in ((4096, 0.5), (16384, 0.1), (64, 0.1), (65536, 0.25)):
+    full = orc.full_size(n, 2.4e6 if n < 65536 else 1e9)
+    x = orc.synth_iq(full, 1).astype(np.complex64)
+    raw = orc.quantize_u8(x * 0.8)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning")
+    for name, fn, arg in (("frame c64", eng.frame, x), ("frame u8", eng.frame, raw), ("curscan c64", eng.curscan, x)):
+        for _ in range(5):
+            fn(arg)
+        t0 = time.perf_counter(); reps = 200
+        for _ in range(reps):
+            fn(arg)
+        dt = (time.perf_counter() - t0) / reps
+        print("N=%-6d q=%-4s %-12s %8.1f us/block  %7.1f MS/s  (%d windows)" % (n, q, name, dt * 1e6, full / dt / 1e6, eng.num_windows))
+    eng.close()
