@@ -79,6 +79,7 @@ struct ksa_engine {
   float* d_scan_state = nullptr;  // [4][total]
   float* d_scan_hm = nullptr;     // [128][scan_hm_width]
   float* d_levels = nullptr;      // [4][cells] plot-side decimation scratch
+  float* d_parts = nullptr;       // [capacity][N] partial folds of the window-split (latency) mode
   int levels_cap = 0;
   ksa::FourStep four;           // N > 16384
   // bookkeeping
@@ -124,8 +125,22 @@ int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
     }
     return 0;
   }
-  const int grid = std::max(1, std::min(p.nframes, e->num_cu * e->blocks_per_cu));
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), lds_bytes, e->stream, p);
+  const int capacity = e->num_cu * e->blocks_per_cu;
+  SpecParams q = p;
+  // small batches (the per-frame drop-in, one scan pass): split every frame's windows over several
+  // workgroups so that the GPU is filled; the partial folds are combined by a second, tiny kernel
+  // (pays from N = 1024 up: 84 -> 51 us per block at N=4096, 720 -> 117 us at N=16384; tiny transforms only lose the launches)
+  if (e->d_parts && N >= 1024 && !getenv("KSA_NO_SPLIT") && p.nwin > 1 && p.nframes * 2 <= capacity) {
+    q.parts = std::min(p.nwin, capacity / p.nframes);
+    q.part_out = e->d_parts;
+  }
+  const int grid = std::max(1, std::min(q.nframes * std::max(1, q.parts), capacity));
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), lds_bytes, e->stream, q);
+  if (q.parts > 1) {
+    hipLaunchKernelGGL(ksa::combine_parts_kernel, dim3((N / 4 + 63) / 64, q.nframes), dim3(64), 0, e->stream, q, N);
+    if (q.hm_w > 0)
+      hipLaunchKernelGGL(ksa::rowmax_batch, dim3((q.hm_w + 255) / 256, q.nframes), dim3(256), 0, e->stream, q, N);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -436,6 +451,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   ALLOC(e->d_partial, 4 * nn * 4);
   ALLOC(e->d_state, 4 * nn * 4);
   if (cfg->hm_width) ALLOC(e->d_hm, (size_t)KSA_HM_ROWS * cfg->hm_width * 4);
+  if (e->path == 0) ALLOC(e->d_parts, (size_t)e->num_cu * e->blocks_per_cu * nn * 4);
   if (cfg->scan_total_entries) {
     ALLOC(e->d_scan_state, (size_t)4 * cfg->scan_total_entries * 4);
     ALLOC(e->d_scan_hm, (size_t)KSA_HM_ROWS * cfg->scan_hm_width * 4);
@@ -455,7 +471,7 @@ void ksa_destroy(ksa_engine* e) {
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   void* ptrs[] = {e->d_starts, e->d_start_last, e->d_window, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
                   e->d_iq_stage, e->d_frames, e->d_part, e->d_partial, e->d_state, e->d_hm, e->d_scan_state, e->d_scan_hm,
-                  e->d_levels};
+                  e->d_levels, e->d_parts};
   for (void* p : ptrs) if (p) hipFree(p);
   ksa::fourstep_destroy(e->four);
   delete e;

@@ -42,6 +42,8 @@ struct SpecParams {
   float* hm_ring;           // [128][hm_w] or null
   int hm_index0;            // ring row of frame 0
   int hm_first;             // first frame stored in the ring
+  int parts;                // > 1: each frame's windows are split over `parts` workgroups (small batches)
+  float* part_out;          // [nframes*parts][N] partial folds (natural bin order), combined by combine_parts_kernel
   unsigned long long* dbg;  // diagnostic builds only (-DKSA_STAMPS): [grid][16] cycle sums; null otherwise
 };
 
@@ -243,8 +245,8 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
 
   if constexpr (WIN_LDS) __syncthreads();   // taps are read before the first exchange barrier
 
-  const int rounds = (p.nwin + S - 1) / S;
   const int nm1 = p.nwin - 1;
+  const int NP = p.parts > 1 ? p.parts : 1;   // window split: latency mode for batches smaller than the GPU
 
   // Raw IQ of one window per thread: 16 samples l + L*q, loaded at the top of the window (8 B/lane, 512 B per
   // wave-instruction).  The buffer descriptor is built from scalars only (a per-lane descriptor makes hipcc wrap
@@ -282,15 +284,19 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   unsigned long long t_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
 #endif
-  for (int frame = blockIdx.x; frame < p.nframes; frame += gridDim.x) {
+  for (int vf = blockIdx.x; vf < p.nframes * NP; vf += gridDim.x) {
+    const int frame = vf / NP, part = vf - frame * NP;
+    // this workgroup's contiguous share of the frame's windows (contiguous keeps the sample reuse valid)
+    const int k_lo = (int)((long long)p.nwin * part / NP), k_hi = (int)((long long)p.nwin * (part + 1) / NP);
+    const int rounds = (k_hi - k_lo + S - 1) / S;
     float acc[16];
     const float init = p.cumu == CUMU_MIN ? __builtin_inff() : 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = init;
 
     for (int rd = 0; rd < rounds; ++rd) {
-      const int k = S == 1 ? rd : rd * S + slot;   // wave-uniform when one transform fills the workgroup
-      const bool active = S == 1 || k < p.nwin;
+      const int k = k_lo + (S == 1 ? rd : rd * S + slot);   // wave-uniform when one transform fills the workgroup
+      const bool active = S == 1 || k < k_hi;
       float2 v[16];
       if (active) issue_loads(frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
       if (active) {
@@ -412,7 +418,25 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
 #ifdef KSA_ABL_NOFIN   // timing-only ablation build: one store per thread keeps the fold alive
     if (red[tid] == 123.456f) p.out[tid] = red[tid];
 #else
-    finish_frame<N, T, S>(p, red, frame, tid);
+    if (NP == 1) {
+      finish_frame<N, T, S>(p, red, frame, tid);
+    } else {
+      // partial fold of this share, slots combined, natural bin order; combine_parts_kernel finishes the frame
+      float4* const dst = reinterpret_cast<float4*>(p.part_out + (long long)vf * N);
+      const float4* red4 = reinterpret_cast<const float4*>(red);
+      for (int q = tid; q < N / 4; q += T) {
+        float4 r = red4[q];
+        if constexpr (S > 1) {
+          for (int s2 = 1; s2 < S; ++s2) {
+            const float4 x = red4[s2 * (N / 4) + q];
+            if (p.cumu == CUMU_AVG) { r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+            else if (p.cumu == CUMU_MAX) { r.x = fmaxf(r.x, x.x); r.y = fmaxf(r.y, x.y); r.z = fmaxf(r.z, x.z); r.w = fmaxf(r.w, x.w); }
+            else { r.x = fminf(r.x, x.x); r.y = fminf(r.y, x.y); r.z = fminf(r.z, x.z); r.w = fminf(r.w, x.w); }
+          }
+        }
+        dst[q] = r;
+      }
+    }
 #endif
     KSA_STAMP(8);
   }
@@ -421,6 +445,37 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
     for (int i = 0; i < 10; ++i) p.dbg[((long long)blockIdx.x * (T / 64) + tid / 64) * 10 + i] = seg[i];
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Window-split (latency) mode: a frame's windows were folded by `parts` workgroups; this combines their
+// partial folds in part order and applies the same scale / fftshift / dB as finish_frame.  One thread =
+// 4 consecutive bins, blockIdx.y = frame.  Waterfall rows follow from rowmax_batch.
+__global__ void combine_parts_kernel(const SpecParams p, int n) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q * 4 >= n) return;
+  const int frame = blockIdx.y;
+  const float4* src = reinterpret_cast<const float4*>(p.part_out + (long long)frame * p.parts * n) + q;
+  float4 r = src[0];
+  for (int part = 1; part < p.parts; ++part) {
+    const float4 x = src[(long long)part * (n / 4)];
+    if (p.cumu == CUMU_AVG) { r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
+    else if (p.cumu == CUMU_MAX) { r.x = fmaxf(r.x, x.x); r.y = fmaxf(r.y, x.y); r.z = fmaxf(r.z, x.z); r.w = fmaxf(r.w, x.w); }
+    else { r.x = fminf(r.x, x.x); r.y = fminf(r.y, x.y); r.z = fminf(r.z, x.z); r.w = fminf(r.w, x.w); }
+  }
+  float o[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    float lin = p.cumu == CUMU_AVG ? o[u] : __builtin_amdgcn_sqrtf(o[u]);
+    lin *= p.scale;
+    o[u] = lin;
+    if (p.out_mode != OUT_LINEAR) {
+      if (p.out_mode == OUT_DB_CLIP) lin = fmaxf(lin, p.min_amp);
+      o[u] = db_of(lin, p.gain);
+    }
+  }
+  const int sh = (4 * q + n / 2) & (n - 1);
+  *reinterpret_cast<float4*>(p.out + (long long)frame * n + sh) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
