@@ -9,7 +9,7 @@
 One "step" = one pass of the whole hot path (IQ -> window -> FFT -> |X| -> fold -> dB -> Cur/Max/Min/Avg
 + waterfall rows) over one HBM-resident batch of `--frames` capture blocks per GPU.  With N > 1 every rank
 owns a contiguous time chunk of the run (weak scaling: frames per GPU fixed), and the global Max/Min/Avg/Cur
-curves come from one fused RCCL all-reduce set per step (distributed.py).  Rank 0 prints ONE JSON line.
+curves and the waterfall ring come from ONE RCCL all-gather + a local merge kernel per step (distributed.py).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib
@@ -193,7 +193,7 @@ def main():
             "config": {"workload": "configs[1]: zeroSpan synthetic 2.4 MS/s IQ, fftSize=4096, 50% overlap, hanning",
                        "input": "complex64" if args.fmt == "c64" else "uint8", "frames_per_gpu_per_step": frames,
                        "samples_per_frame": FULL, "windows_per_frame": nwin, "sharding": "time-chunk",
-                       "collective": "RCCL: 1 MAX + 1 SUM all-reduce of [N] curves + 1 ring broadcast per step" if world > 1 else "none"},
+                       "collective": "RCCL: 1 all-gather of [4N + 128W] floats per rank per step, merged by ksa_merge_gathered_dev" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ksa::spectrum_kernel<4096,%s>" % ("c64" if args.fmt == "c64" else "u8"),

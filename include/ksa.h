@@ -101,6 +101,17 @@ int ksa_frame_spectrum(ksa_engine* e, const float* mag_host /* [fft_size], fftsh
  * the ranks that share a run, then ksa_commit on every rank. */
 int ksa_partial_dev(ksa_engine* e, float** partial_dev);
 int ksa_commit(ksa_engine* e, int64_t total_frames);
+/* One-collective form of the same merge.  The partial block and the waterfall ring are one contiguous device
+ * block, float[4*N + KSA_HM_ROWS*hm_width] (`nfloats`): all-gather it across the ranks (rank order) and hand
+ * the gathered float[world][nfloats] to ksa_merge_gathered_dev, which reduces the partial rows (sum in rank
+ * order: the same bits on every rank), takes every ring row from the rank that holds the newest frame mapped
+ * to it (global frame f of the run lives in ring row (hm_index0 + f) % 128; rank r holds frames
+ * [r*frames_per_rank, (r+1)*frames_per_rank)), and commits world*frames_per_rank frames.  Each rank must have
+ * set its ring position to (hm_index0 + rank*frames_per_rank) % 128 (ksa_set_hm_index) before its
+ * ksa_frames_dev(commit=0); afterwards the ring position is (hm_index0 + world*frames_per_rank) % 128. */
+int ksa_exchange_dev(ksa_engine* e, float** xchg_dev, int64_t* nfloats);
+int ksa_merge_gathered_dev(ksa_engine* e, const float* gathered_dev, int32_t world, int32_t frames_per_rank,
+                           int32_t hm_index0);
 /* GUI toggles bDataMax/bDataMin/bDataAvg (K:71-73, K:471-476) */
 int ksa_set_flags(ksa_engine* e, int32_t b_max, int32_t b_min, int32_t b_avg);
 /* d['Fft.Adj'] subtracted before the waterfall row (K:400-411, K:478-480); NULL clears. */

@@ -51,6 +51,8 @@ SIGNATURES = {
     "ksa_frame_spectrum": (C.c_int, [_P, _P]),
     "ksa_partial_dev": (C.c_int, [_P, C.POINTER(_P)]),
     "ksa_commit": (C.c_int, [_P, _I64]),
+    "ksa_exchange_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "ksa_merge_gathered_dev": (C.c_int, [_P, _P, _I32, _I32, _I32]),
     "ksa_set_flags": (C.c_int, [_P, _I32, _I32, _I32]),
     "ksa_set_adj": (C.c_int, [_P, _P, _I32]),
     "ksa_reset_state": (C.c_int, [_P]),

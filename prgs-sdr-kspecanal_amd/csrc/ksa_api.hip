@@ -73,9 +73,10 @@ struct ksa_engine {
   void* d_iq_stage = nullptr;   // one block for the host-pointer entry points
   float* d_frames = nullptr;    // [max_frames][N] per-frame spectra when the caller passes none
   float* d_part = nullptr;      // [chunks][3][N]
-  float* d_partial = nullptr;   // [4][N]
+  float* d_xchg = nullptr;      // one block [4][N] partial | [128][hm_width] ring: what a rank sends to the others
+  float* d_partial = nullptr;   // [4][N]            (= d_xchg)
   float* d_state = nullptr;     // [4][N] cur,max,min,avg
-  float* d_hm = nullptr;        // [128][hm_width]
+  float* d_hm = nullptr;        // [128][hm_width]   (= d_xchg + 4N)
   float* d_scan_state = nullptr;  // [4][total]
   float* d_scan_hm = nullptr;     // [128][scan_hm_width]
   float* d_levels = nullptr;      // [4][cells] plot-side decimation scratch
@@ -448,9 +449,10 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   ALLOC(e->d_iq_stage, (size_t)cfg->full_size * 8);
   ALLOC(e->d_frames, (size_t)cfg->max_frames * nn * 4);
   ALLOC(e->d_part, (size_t)e->max_chunks * 3 * nn * 4);
-  ALLOC(e->d_partial, 4 * nn * 4);
+  ALLOC(e->d_xchg, (4 * nn + (size_t)KSA_HM_ROWS * cfg->hm_width) * 4);
+  e->d_partial = e->d_xchg;
+  if (cfg->hm_width) e->d_hm = e->d_xchg + 4 * nn;
   ALLOC(e->d_state, 4 * nn * 4);
-  if (cfg->hm_width) ALLOC(e->d_hm, (size_t)KSA_HM_ROWS * cfg->hm_width * 4);
   if (e->path == 0) ALLOC(e->d_parts, (size_t)e->num_cu * e->blocks_per_cu * nn * 4);
   if (cfg->scan_total_entries) {
     ALLOC(e->d_scan_state, (size_t)4 * cfg->scan_total_entries * 4);
@@ -470,7 +472,7 @@ void ksa_destroy(ksa_engine* e) {
   hipDeviceSynchronize();
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   void* ptrs[] = {e->d_starts, e->d_start_last, e->d_window, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
-                  e->d_iq_stage, e->d_frames, e->d_part, e->d_partial, e->d_state, e->d_hm, e->d_scan_state, e->d_scan_hm,
+                  e->d_iq_stage, e->d_frames, e->d_part, e->d_xchg, e->d_state, e->d_scan_state, e->d_scan_hm,
                   e->d_levels, e->d_parts};
   for (void* p : ptrs) if (p) hipFree(p);
   ksa::fourstep_destroy(e->four);
@@ -564,6 +566,34 @@ int ksa_frame_spectrum(ksa_engine* e, const float* mag_host) {
 int ksa_partial_dev(ksa_engine* e, float** partial_dev) {
   if (!e || !partial_dev) return fail("null argument");
   *partial_dev = e->d_partial;
+  return 0;
+}
+
+int ksa_exchange_dev(ksa_engine* e, float** xchg_dev, int64_t* nfloats) {
+  if (!e || !xchg_dev || !nfloats) return fail("null argument");
+  *xchg_dev = e->d_xchg;
+  *nfloats = 4ll * e->cfg.fft_size + (long long)KSA_HM_ROWS * e->cfg.hm_width;
+  return 0;
+}
+
+int ksa_merge_gathered_dev(ksa_engine* e, const float* gathered_dev, int32_t world, int32_t frames_per_rank,
+                           int32_t hm_index0) {
+  if (!e || !gathered_dev) return fail("null argument");
+  if (world < 1) return fail("world %d < 1", world);
+  if (frames_per_rank < 1) return fail("frames_per_rank %d < 1", frames_per_rank);
+  if (e->pending_frames != frames_per_rank)
+    return fail("ksa_merge_gathered_dev: %d frames pending, frames_per_rank says %d", e->pending_frames, frames_per_rank);
+  if (hm_index0 < 0 || hm_index0 >= KSA_HM_ROWS) return fail("hm_index0 %d outside 0..127", hm_index0);
+  HIP_OK(hipSetDevice(e->cfg.device));
+  const int n = e->cfg.fft_size, w = e->cfg.hm_width;
+  const long long stride = 4ll * n + (long long)KSA_HM_ROWS * w;
+  const long long total = (long long)world * frames_per_rank;
+  const long long cells = std::max<long long>(n, (long long)KSA_HM_ROWS * w);
+  hipLaunchKernelGGL(ksa::merge_gathered_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, e->stream,
+                     gathered_dev, world, stride, n, e->d_partial, e->d_hm, w, hm_index0, frames_per_rank, total);
+  HIP_OK(hipGetLastError());
+  if (do_commit(e, total, 0)) return 1;
+  e->hm_index = (int)((hm_index0 + total) % KSA_HM_ROWS);
   return 0;
 }
 

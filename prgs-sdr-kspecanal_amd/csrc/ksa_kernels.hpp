@@ -600,6 +600,34 @@ __global__ __launch_bounds__(1024) void accumulate_reduce_kernel(const float* pa
   }
 }
 
+// Multi-GPU merge (no reference counterpart; algebra of SURVEY.md 8(e)): `g` is the all-gather of every rank's
+// exchange block [4][N] partial | [128][W] ring, `stride` floats apart, in rank order.  Thread i < N reduces the
+// partial rows (max | cur | -min by NaN-propagating max, the weighted sum in rank order: deterministic, the same
+// bits on every rank); thread c < 128*W picks ring cell c from the rank whose chunk holds the newest frame that
+// maps to that ring slot (global frame f lives in slot (idx0 + f) % 128; rank r holds frames [r*fpr, (r+1)*fpr)).
+__global__ void merge_gathered_kernel(const float* g, int world, long long stride, int n, float* partial, float* hm,
+                                      int hm_w, int idx0, int fpr, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float mx = g[i], cur = g[n + i], nmn = g[2 * n + i], sum = g[3 * n + i];
+    for (int r = 1; r < world; ++r) {
+      const float* s = g + r * stride;
+      mx = nan_max(mx, s[i]);
+      cur = nan_max(cur, s[n + i]);
+      nmn = nan_max(nmn, s[2 * n + i]);
+      sum += s[3 * n + i];
+    }
+    partial[i] = mx; partial[n + i] = cur; partial[2 * n + i] = nmn; partial[3 * n + i] = sum;
+  }
+  if (hm && i < (long long)HM_ROWS * hm_w) {
+    const int slot = (int)(i / hm_w);
+    const long long last = total - 1;
+    const long long back = ((idx0 + last - slot) % HM_ROWS + HM_ROWS) % HM_ROWS;
+    const long long f = last - back;      // newest frame of this run stored in `slot`, or < 0: none
+    if (f >= 0) hm[i] = g[(f / fpr) * stride + 4ll * n + i];
+  }
+}
+
 // state layout: [cur | max | min | avg]
 __global__ void commit_kernel(const float* partial, float* state, int n, int has_prev,
                               long long total_frames, int b_max, int b_min, int b_avg) {

@@ -12,10 +12,12 @@ G*F frames and the accumulators are merged with the algebra of SURVEY.md 8(e):
   waterfall -> the ring keeps the last 128 rows of the run; every rank writes its rows at the globally
                correct ring slots, one all-gather picks each slot from the rank that owns its newest frame.
 
-Message sizes are a few KiB..MiB (latency bound on xGMI), so the collectives are fused: one MAX over
-[max|cur|-min], one SUM, and one broadcast (or all-gather when a rank holds < 128 frames) for the ring --
-per batch, not per frame.
-The tensor algebra below is device agnostic (tested on CPU with gloo, run on GPUs with nccl = RCCL).
+Message sizes are a few KiB..MiB (latency bound on xGMI), so there is ONE collective per batch: every rank's
+partial block and ring are one contiguous device block (4N + 128W floats, 320 KiB at config 2), all-gathered
+in rank order; libksa's merge kernel then reduces and commits locally (ksa_merge_gathered_dev).  Summing in
+rank order makes the result bit-identical on every rank and from run to run, which an all-reduce does not
+promise.  merge_partials/merge_ring are the same algebra as separate all-reduces on plain tensors
+(device agnostic: tested on CPU with gloo), and merge_gathered_reference restates the kernel in torch.
 """
 import torch
 import torch.distributed as dist
@@ -60,6 +62,33 @@ def merge_ring(ring, idx0, frames_per_rank, world, group=None):
     return ring
 
 
+def all_gather_flat(recv, send, group=None):
+    """recv: [world, n] <- every rank's send [n], rank order; one collective."""
+    try:
+        dist.all_gather_into_tensor(recv.view(-1), send, group=group)
+    except (RuntimeError, NotImplementedError, AttributeError):   # backends without the flat form
+        dist.all_gather(list(recv.unbind(0)), send, group=group)
+    return recv
+
+
+def merge_gathered_reference(gathered, n, hm_w, idx0, frames_per_rank):
+    """Torch restatement of ksa::merge_gathered_kernel: gathered [world, 4n + 128*hm_w] -> (partial [4, n],
+    ring rows [128, hm_w] with a mask of the rows this run defines)."""
+    world = gathered.shape[0]
+    parts = gathered[:, :4 * n].reshape(world, 4, n)
+    partial = torch.empty((4, n), dtype=gathered.dtype, device=gathered.device)
+    partial[0:3] = parts[:, 0:3].amax(dim=0)            # amax propagates NaN, as the kernel's nan_max does
+    acc = parts[0, 3].clone()
+    for r in range(1, world):
+        acc = acc + parts[r, 3]                         # rank order
+    partial[3] = acc
+    rings = gathered[:, 4 * n:].reshape(world, HM_ROWS, hm_w)
+    owner = ring_owner(idx0, frames_per_rank, world).to(gathered.device)
+    pick = owner.clamp(min=0).view(1, HM_ROWS, 1).expand(1, HM_ROWS, hm_w)
+    ring = torch.gather(rings, 0, pick)[0]
+    return partial, ring, owner >= 0
+
+
 class ShardedZeroSpan:
     """Drives one engine per rank; with world == 1 it is a plain frames_dev call."""
 
@@ -68,9 +97,8 @@ class ShardedZeroSpan:
         self.hm_index = 0                              # global ring position (identical on all ranks)
         self.collective = world > 1 or always_collective   # always_collective: run the merge path on one rank too
         if self.collective:
-            self._partial = torch.as_tensor(engine.partial(), device="cuda")
-            _, ring = engine.state_dev()
-            self._ring = torch.as_tensor(ring, device="cuda")
+            self._send = torch.as_tensor(engine.exchange(), device="cuda")
+            self._recv = torch.empty((world, self._send.numel()), dtype=torch.float32, device="cuda")
 
     def step(self, iq, fmt, frames, cur_db=None, hm_rows=None):
         """Every rank passes its own `frames` capture blocks (its time chunk of a world*frames run)."""
@@ -83,11 +111,13 @@ class ShardedZeroSpan:
         eng.set_hm_index((self.hm_index + self.rank * frames) % HM_ROWS)
         eng.frames_dev(iq, fmt, frames, first_index=self.rank * frames, total_frames=total,
                        cur_db=cur_db, hm_rows=hm_rows, commit=False)
-        merge_partials(self._partial, self.group)
-        eng.commit(total)
-        merge_ring(self._ring, self.hm_index, frames, self.world, self.group)
+        if self.world > 1 or dist.is_initialized():     # (a one-rank group still exercises the RCCL call)
+            all_gather_flat(self._recv, self._send, self.group)
+            gathered = self._recv
+        else:
+            gathered = self._send                       # always_collective on one rank: the gather is the identity
+        eng.merge_gathered(gathered, self.world, frames, self.hm_index)
         self.hm_index = (self.hm_index + total) % HM_ROWS
-        eng.set_hm_index(self.hm_index)
 
 
 # ------------------------------------------------------------------------------------------------

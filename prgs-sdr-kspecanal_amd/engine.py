@@ -204,6 +204,17 @@ class SpectrumEngine:
         check(lib.ksa_partial_dev(self._h, C.byref(p)))
         return DevArray(p.value, (4, self.fft_size), self)
 
+    def exchange(self):
+        """Device view float32[4*N + 128*W]: the partial block followed by the waterfall ring -- what one rank
+        contributes to the all-gather of a sharded run."""
+        p, n = C.c_void_p(), C.c_int64()
+        check(lib.ksa_exchange_dev(self._h, C.byref(p), C.byref(n)))
+        return DevArray(p.value, (n.value,), self)
+
+    def merge_gathered(self, gathered, world, frames_per_rank, hm_index0):
+        """gathered: device float32[world, 4*N + 128*W] (rank order) -> merged partial + ring, committed."""
+        check(lib.ksa_merge_gathered_dev(self._h, _ptr(gathered), int(world), int(frames_per_rank), int(hm_index0)))
+
     def commit(self, total_frames):
         check(lib.ksa_commit(self._h, int(total_frames)))
 

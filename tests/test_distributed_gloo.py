@@ -48,6 +48,7 @@ def _worker(rank, world, port, frames_per_rank, idx0, out_path):
     mine = x[rank * frames_per_rank:(rank + 1) * frames_per_rank]
     db = np.array([orc.log_no_gain(orc.curscan(fr, N, Q, win, "AVG"), GAIN) for fr in mine])
     part = torch.from_numpy(_partial_from_oracle(db, rank * frames_per_rank, total, False, rank == world - 1))
+    part_local = part.clone()
     ksa_dist.merge_partials(part)
     # ring: every rank writes its rows at the globally correct slots, as the spectrum kernel does
     ring = torch.full((128, XRES), 7.0)          # stale content from "before this run"
@@ -55,9 +56,16 @@ def _worker(rank, world, port, frames_per_rank, idx0, out_path):
     for f in range(first, frames_per_rank):
         g = rank * frames_per_rank + f
         ring[(idx0 + g) % 128] = torch.from_numpy(orc.plotcompress(db[f], XRES, "MAX")).float()
+    ring_local = ring.clone()
     ksa_dist.merge_ring(ring, idx0, frames_per_rank, world)
+    # the one-collective form the GPU path uses: all-gather of [partial | ring], merged locally
+    send = torch.cat([part_local.reshape(-1), ring_local.reshape(-1)])
+    recv = torch.empty((world, send.numel()))
+    ksa_dist.all_gather_flat(recv, send)
+    part1, ring1, defined = ksa_dist.merge_gathered_reference(recv, N, XRES, idx0, frames_per_rank)
+    ring1 = torch.where(defined.view(-1, 1), ring1, ring_local)
     if rank == 0:
-        np.savez(out_path, part=part.numpy(), ring=ring.numpy())
+        np.savez(out_path, part=part.numpy(), ring=ring.numpy(), part1=part1.numpy(), ring1=ring1.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -89,6 +97,10 @@ def test_two_rank_merge_equals_sequential_run(tmp_path, frames_per_rank, idx0):
     for g in range(max(0, total - 128), total):
         want[(idx0 + g) % 128] = orc.plotcompress(db[g], XRES, "MAX")
     assert np.allclose(got["ring"], want, rtol=0, atol=1e-4)
+    # all-gather + local merge: same maxima bit for bit, sum in rank order
+    assert np.array_equal(got["part1"][0:3], got["part"][0:3])
+    assert np.allclose(got["part1"][3], got["part"][3], rtol=0, atol=1e-5)
+    assert np.array_equal(got["ring1"], got["ring"])
 
 
 def test_ring_owner_map():

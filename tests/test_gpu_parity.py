@@ -382,8 +382,8 @@ def test_sharded_scan_driver_world1(ksa, torch_cuda):
 
 
 def test_rccl_merge_path_single_rank(ksa, torch_cuda):
-    """The multi-GPU merge of distributed.ShardedZeroSpan (views of library memory as torch tensors, RCCL
-    all-reduce / all-gather, ksa_commit) driven on a one-rank nccl group must equal the plain path."""
+    """The multi-GPU merge of distributed.ShardedZeroSpan (a view of library memory as the send buffer of an RCCL
+    all-gather, ksa_merge_gathered_dev) driven on a one-rank nccl group must equal the plain path."""
     import os
     import torch.distributed as dist
     torch = torch_cuda
@@ -411,6 +411,70 @@ def test_rccl_merge_path_single_rank(ksa, torch_cuda):
             assert np.array_equal(a[k], b[k]), k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fpr,idx0", [(3, 40, 0), (2, 100, 77), (4, 150, 5), (8, 16, 120)])
+def test_gathered_merge_kernel_emulated_ranks(ksa, torch_cuda, world, fpr, idx0):
+    """ksa_merge_gathered_dev with the ranks of a sharded run emulated on one GPU: every "rank" (its own engine)
+    processes its time chunk uncommitted, the exchange blocks are stacked as an all-gather would deliver them,
+    and each rank's merge must equal (a) a single engine running the whole run and (b) the torch restatement
+    of the kernel.  Two steps, so that stale ring rows and the has-previous path are covered."""
+    torch = torch_cuda
+    dmod = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
+    n, full, xres = 1024, 4096, 128
+    total = world * fpr
+    x = orc.synth_iq(full * total * 2, 31 + world).astype(np.complex64).reshape(2, total, full)
+    dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+    mk = lambda mf: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=xres,
+                                       max_frames=mf, stream=torch.cuda.current_stream().cuda_stream)
+    one = mk(total)
+    one.set_hm_index(idx0)
+    ranks = [mk(fpr) for _ in range(world)]
+    hm_index = idx0
+    for step in range(2):
+        one.frames_dev(dev[step], ksa.FMT_C64, total)
+        for r, eng in enumerate(ranks):
+            eng.set_hm_index((hm_index + r * fpr) % 128)
+            eng.frames_dev(dev[step, r * fpr:(r + 1) * fpr], ksa.FMT_C64, fpr, first_index=r * fpr, total_frames=total,
+                           commit=False)
+        gathered = torch.stack([torch.as_tensor(eng.exchange(), device="cuda").clone() for eng in ranks])
+        ref_partial, ref_ring, defined = dmod.merge_gathered_reference(gathered, n, xres, hm_index, fpr)
+        for eng in ranks:
+            eng.merge_gathered(gathered, world, fpr, hm_index)
+        torch.cuda.synchronize()
+        hm_index = (hm_index + total) % 128
+        want = one.state()
+        for r, eng in enumerate(ranks):
+            got = eng.state()
+            assert got["frames"] == want["frames"] and got["hm_index"] == want["hm_index"] == hm_index
+            # (tolerance, not equality: small chunks run in window-split mode, which folds in another order)
+            for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg", "fftHM"):
+                assert_db(got[k], want[k], what="%s rank %d step %d" % (k, r, step))
+            part = torch.as_tensor(eng.partial(), device="cuda").cpu().numpy()
+            assert np.array_equal(part, ref_partial.cpu().numpy()), ("partial vs torch restatement", r, step)
+            rows = np.flatnonzero(defined.cpu().numpy())
+            assert np.array_equal(got["fftHM"][rows], ref_ring.cpu().numpy()[rows].astype(np.float64))
+    # every rank holds the same bits
+    a = ranks[0].state()
+    for eng in ranks[1:]:
+        b = eng.state()
+        assert all(np.array_equal(a[k], b[k]) for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg", "fftHM"))
+    for eng in ranks + [one]:
+        eng.close()
+
+
+def test_merge_gathered_refusals(ksa, torch_cuda):
+    torch = torch_cuda
+    eng = ksa.SpectrumEngine(256, full_size=1024, non_overlap=0.5, max_frames=8)
+    buf = torch.zeros((2, 4 * 256 + 128 * eng.hm_width), dtype=torch.float32, device="cuda")
+    with pytest.raises(ksa.KsaError):
+        eng.merge_gathered(buf, 2, 4, 0)                      # nothing pending
+    x = torch.zeros((4, 1024, 2), dtype=torch.float32, device="cuda")
+    eng.frames_dev(x, ksa.FMT_C64, 4, first_index=0, total_frames=8, commit=False)
+    for bad in ((0, 4, 0), (2, 3, 0), (2, 4, 128), (2, 4, -1)):
+        with pytest.raises(ksa.KsaError):
+            eng.merge_gathered(buf, *bad)
+    eng.close()
 
 
 @pytest.mark.parametrize("n,xres", [(128, 64), (64, 64), (1024, 512), (4096, 16), (16384, 32), (16384, 8192), (256, 4), (65536, 64)])
