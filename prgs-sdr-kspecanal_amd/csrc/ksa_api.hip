@@ -146,10 +146,13 @@ int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
   return 0;
 }
 
-// sample-reuse variants exist where one transform fills the workgroup (N >= 1024)
+// sample-reuse variants exist where one transform fills the workgroup and the carried samples fit the register
+// budget (N = 1024..4096).  At T >= 512 (128-VGPR cap) the carried registers spill: measured 9..28 % slower than
+// re-reading the overlap through L2 (N=8192: 42.6 vs 46.3 M FFT/s at 50 %, 40.7 vs 51.9 at 75 %; N=16384: 20.4 vs
+// 23.3 and 19.7 vs 25.0), so those sizes take the general path.
 template <int N, int FMT>
 int launch_spec_rm(ksa_engine* e, const SpecParams& p, bool cfg_only, int rm) {
-  if constexpr (ksa::Plan<N>::S == 1) {
+  if constexpr (ksa::Plan<N>::S == 1 && ksa::Plan<N>::T <= 256) {
     if (rm == 8) return launch_spec_t<N, FMT, 8>(e, p, cfg_only);
     if (rm == 4) return launch_spec_t<N, FMT, 4>(e, p, cfg_only);
   }
