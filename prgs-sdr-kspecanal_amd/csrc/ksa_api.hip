@@ -106,10 +106,29 @@ namespace {
 
 using ksa::SpecParams;
 
+template <int N, int FMT, int RM, int CM>
+int launch_spec_c(ksa_engine* e, const SpecParams& p, bool configure_only);
+
 template <int N, int FMT, int RM>
 int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
+  // fold mode as a template constant (Tune<N>::fold_const) or as a run-time branch inside the window loop
+  if constexpr (ksa::Tune<N>::fold_const(RM)) {
+    if (configure_only) {
+      if (launch_spec_c<N, FMT, RM, ksa::CUMU_MAX>(e, p, true) || launch_spec_c<N, FMT, RM, ksa::CUMU_MIN>(e, p, true)) return 1;
+      return launch_spec_c<N, FMT, RM, ksa::CUMU_AVG>(e, p, true);
+    }
+    if (p.cumu == ksa::CUMU_AVG) return launch_spec_c<N, FMT, RM, ksa::CUMU_AVG>(e, p, false);
+    if (p.cumu == ksa::CUMU_MAX) return launch_spec_c<N, FMT, RM, ksa::CUMU_MAX>(e, p, false);
+    return launch_spec_c<N, FMT, RM, ksa::CUMU_MIN>(e, p, false);
+  } else {
+    return launch_spec_c<N, FMT, RM, 0>(e, p, configure_only);
+  }
+}
+
+template <int N, int FMT, int RM, int CM>
+int launch_spec_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
   using P = ksa::Plan<N>;
-  auto kfn = ksa::spectrum_kernel<N, FMT, RM>;
+  auto kfn = ksa::spectrum_kernel<N, FMT, RM, CM>;
   static const int lds_pad = getenv("KSA_LDS_PAD_KB") ? atoi(getenv("KSA_LDS_PAD_KB")) * 1024 : 0;   // occupancy experiments
   const int lds_bytes = ksa::Tune<N>::LDS_BYTES + lds_pad;
   if (configure_only) {

@@ -192,13 +192,20 @@ struct Tune {
   static constexpr bool WIN_GLOBAL = Plan<N>::T >= 512;
 #endif
   static constexpr int LDS_BYTES = Plan<N>::LDS_BYTES + (WIN_LDS ? N * 4 : 0);
+  // Fold mode (AVG/MAX/MIN) as a template constant of the kernel instead of a branch inside the window loop:
+  // with the branch, hipcc copies the 16 accumulators to and from the branch's registers in every window (32
+  // v_mov of ~700 VALU instructions) and schedules around three merge points.  Measured over N = 16..16384 x
+  // hops 0.5/0.25/0.1 (tools/fold_sweep.sh): constant wins everywhere (+2..+58 %, e.g. N=1024 75 % overlap
+  // 1.23 -> 0.78 ms, N=64 0.60 -> 0.45 ms) except N=4096 on the general path, where the constant form makes
+  // hipcc serialise the loads (155 VGPRs, 1.95 vs 1.75 ms) -- that one keeps the run-time branch.
+  static constexpr bool fold_const(int rm) { return !(N == 4096 && rm == 0); }
 };
 
 // RM > 0: consecutive windows are exactly RM*L samples apart (L = N/16 threads), so thread l's samples
 // l + L*q of window k+1 are its samples q+RM of window k: the raw values stay in VGPRs and only RM new
 // samples per thread are loaded per window (50 % overlap: RM = 8, 75 %: RM = 4).  Each IQ sample is then
 // read from HBM exactly once.  RM = 0 is the general path (fractional hops, K:386).
-template <int N, int FMT, int RM>
+template <int N, int FMT, int RM, int CM>
 __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(const SpecParams p) {
   static_assert(RM == 0 || Plan<N>::S == 1, "sample reuse needs one transform per workgroup");
   using P = Plan<N>;
@@ -388,14 +395,15 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       }
       // ---- |X| and the fold over this block's windows (K:391-395) ----------------------------
       if (active) {
-        if (p.cumu == CUMU_AVG) {
+        const int cm = CM == 0 ? p.cumu : CM;   // CM != 0: the fold mode is a compile-time constant
+        if (cm == CUMU_AVG) {
           // closed form of the (a+x)/2 recursion: weight 2^-(n-k+1), first window 2^-n
           const int e = k == 0 ? nm1 : nm1 - k + 1;
           const float w = ldexpf(1.0f, -e);
 #pragma unroll
           for (int i = 0; i < 16; ++i)
             acc[i] = fmaf(w, __builtin_amdgcn_sqrtf(fmaf(v[i].x, v[i].x, v[i].y * v[i].y)), acc[i]);
-        } else if (p.cumu == CUMU_MAX) {
+        } else if (cm == CUMU_MAX) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
         } else {
