@@ -106,7 +106,15 @@ def main():
     ap.add_argument("--fmt", choices=("c64", "u8"), default="c64")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N=1 only: run the multi-GPU merge path (all-gather + merge kernel) on a one-rank group, to price its fixed cost")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON): native libraries that print to fd 1 (RCCL's version banner
+    # does) are sent to stderr for the whole run, the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -127,6 +135,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    elif args.force_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group(backend, rank=0, world_size=1, device_id=torch.device("cuda", local) if backend == "nccl" else None)
 
     frames = args.frames
     sb = 8 if args.fmt == "c64" else 2
@@ -148,7 +160,7 @@ def main():
                              max_frames=frames, device=local, stream=torch.cuda.current_stream().cuda_stream)
     cur_db = torch.empty((frames, N_FFT), dtype=torch.float32, device="cuda")
     hm_rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
-    run = ksa_dist.ShardedZeroSpan(eng, rank, world)
+    run = ksa_dist.ShardedZeroSpan(eng, rank, world, always_collective=args.force_collective)
 
     def step():
         run.step(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
@@ -215,9 +227,11 @@ def main():
             multi = cpu_baseline_multicore()
             if multi is not None:
                 out["cpu_baseline_multicore"] = multi
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
