@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=16384, help="capture blocks per GPU per step (16384 = 4 GiB of complex64)")
+    ap.add_argument("--frames", type=int, default=65536, help="capture blocks per GPU per step (65536 = 16 GiB of complex64 resident in HBM)")
     ap.add_argument("--fmt", choices=("c64", "u8"), default="c64")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
