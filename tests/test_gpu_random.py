@@ -77,3 +77,58 @@ def test_random_configuration(ksa, case):
     # the host-pointer drop-in agrees with the batched path
     assert_lin(eng.curscan(xin[0] if fmt == "c64" else raw[0]), lin_ref[0], what="host curscan")
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ scan stitch
+def _scan_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        n = int(rng.choice([64, 128, 256, 512, 1024, 4096]))
+        sq = float(rng.choice([0.5, 0.25, 0.75, 1.0, 0.125]))          # scanRangeNonOverlap with an integer hop
+        fs = 2.4e6
+        groups = int(rng.integers(1, 9 if n <= 1024 else 4))
+        frac = float(rng.choice([0.0, 0.3, 0.77]))                     # span not a multiple of the sampling rate
+        start = 88e6 + float(rng.integers(0, 10)) * 1e5
+        end = start + (groups + frac) * fs
+        passes = int(rng.choice([1, 2, 3, 5]))
+        out.append((i, n, sq, start, end, fs, passes, str(rng.choice(WINDOWS)), bool(rng.random() < 0.3),
+                    float(rng.choice([0.1, 0.5])), int(2 ** rng.integers(3, 10)), bool(rng.random() < 0.4)))
+    return out
+
+
+@pytest.mark.parametrize("case", _scan_cases(24 if not SOAK else COUNT // 4, SEED + 1),
+                         ids=lambda c: "s%d-N%d-sq%s-p%d" % (c[0], c[1], c[2], c[6]))
+def test_random_scan(ksa, case):
+    """Scan passes (K:568-698: clip, dB, RAW/AVG stitch, Max/Min/Avg, waterfall row per pass) with random geometry,
+    dummy bands (K:637-639) and bScanRangeBaseDataIsRaw (K:651-662) against the oracle's ScanState."""
+    import torch
+    i, n, sq, start, end, fs, passes, window, base_raw, q, xres, dummies = case
+    end, _ = orc.fixup_scan_range(start, end, fs)          # K:701-709: the span becomes a whole number of bands
+    steps = len(orc.scan_steps(start, end, fs, sq))
+    if steps < 1:
+        pytest.skip("empty scan range")
+    full = 2 * n
+    total = int((end - start) / fs) * n                    # K:599-600
+    if total % xres:
+        xres = n                                           # the reference's reshape (K:188-200) needs a divisor
+    ref = orc.ScanState(n, start, end, fs, 19.1, 1e-7, xres, scan_non_overlap=sq, base_is_raw=base_raw)
+    assert ref.total == total
+    win = orc.window_table(window, n)
+    rng = np.random.default_rng(900 + i)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=window, gain=19.1, min_amp=1e-7, xres=xres,
+                             max_frames=steps, scan_total_entries=ref.total, scan_non_overlap=sq)
+    eng.scan_set_base_is_raw(base_raw)
+    for p in range(passes):
+        x = (orc.synth_iq(full * steps, 7000 + 10 * i + p) * (0.3 + 0.5 * rng.random())).astype(np.complex64).reshape(steps, full)
+        ok = np.ones(steps, dtype=np.uint8)
+        if dummies:
+            ok[rng.integers(0, steps, size=max(1, steps // 5))] = 0
+        ref.run_pass([orc.curscan(x[s], n, q, win, "AVG") if ok[s] else None for s in range(steps)])
+        eng.scan_pass_dev(torch.view_as_real(torch.from_numpy(x)).cuda(), ksa.FMT_C64, steps, step_ok=ok)
+    st = eng.scan_state()
+    assert st["passes"] == passes and st["hm_index"] == ref.hm_index
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], getattr(ref, k), what="scan " + k)
+    assert_db(st["fftHM"][:min(passes, 128)], ref.hm[:min(passes, 128)], what="scan waterfall")
+    eng.close()
