@@ -1,6 +1,7 @@
 """The kspecanal-compatible front end (prgs-sdr-kspecanal_amd/kspecanal.py) end to end on the GPU: the dict `d`
 it leaves behind -- the reference's plotting hand-off -- against the oracle fed with the very blocks the
 (recording) source delivered."""
+import os
 import pickle
 
 import numpy as np
@@ -146,3 +147,30 @@ def test_zero_span_from_raw_rtl_sdr_capture(tmp_path):
     d = mod.main(["zeroSpan", "fftSize", str(n), "window", "hamming", "curScanNonOverlap", "0.5", "prgLoopCnt", "9",
                   "iqFormat", "u8", "bPltLevels", "false", "bPltHeatMap", "false", "source", "file:%s" % path])
     assert d["cmd.stop"] is True
+
+
+def test_bench_contract_one_json_line():
+    """bench.py prints exactly one line on stdout -- the JSON the driver parses -- with the contract's keys, the
+    roofline and cpu_baseline objects, and nothing else there (RCCL and friends are kept on stderr)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--frames", "2048", "--cpu-seconds", "1", "--force-collective"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "FFT/s" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["launches"] == 3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
+    assert abs(d["value"] - 2048 * 15 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-9
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "FFT/s" and cb["value"] > 0 and cb["sample"]
