@@ -201,7 +201,13 @@ struct Tune {
   // hops 0.5/0.25/0.1 (tools/fold_sweep.sh): constant wins everywhere (+2..+58 %, e.g. N=1024 75 % overlap
   // 1.23 -> 0.78 ms, N=64 0.60 -> 0.45 ms) except N=4096 on the general path, where the constant form makes
   // hipcc serialise the loads (155 VGPRs, 1.95 vs 1.75 ms) -- that one keeps the run-time branch.
+#if defined(KSA_FOLD_GENERIC)     // tools/fold_sweep.sh: the run-time branch everywhere
+  static constexpr bool fold_const(int) { return false; }
+#elif defined(KSA_FOLD_CONST_ALL) // ... and the template constant everywhere
+  static constexpr bool fold_const(int) { return true; }
+#else
   static constexpr bool fold_const(int rm) { return !(N == 4096 && rm == 0); }
+#endif
 };
 
 // RM > 0: consecutive windows are exactly RM*L samples apart (L = N/16 threads), so thread l's samples
