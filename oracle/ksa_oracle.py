@@ -161,6 +161,38 @@ def heatmap_width(fft_size, xres):
     return xres if fft_size > xres else fft_size
 
 
+# ----------------------------------------------------- (f2) plot-side reductions
+def data_plotcompress(x, y, xres, mode):
+    """K:205-221: the x axis is group-averaged, y reduced with `mode`; RAW passes both through."""
+    if mode == "RAW":
+        return x, y
+    return plotcompress(x, xres, "AVG"), plotcompress(y, xres, mode)
+
+
+def plot_highs(freqs, levels, delta_frac, num_markers):
+    """Peak markers of plot_highs (K:243-272) as a list of (freq, level): walk the points from the highest
+    level down, mark one unless an already marked frequency lies closer than delta_frac * (freqs[-1]-freqs[0])
+    (K:249-250, K:261-262), stop after num_markers (K:268-269).  The walk covers i = -1 .. -(len-1) of the
+    ascending argsort (K:258), i.e. the lowest point is never visited."""
+    delta = delta_frac * (freqs[-1] - freqs[0])
+    order = np.argsort(levels)
+    marked = []
+    for j in range(1, len(freqs)):
+        i = order[-j]
+        if all(abs(f - freqs[i]) >= delta for f, _ in marked):
+            marked.append((float(freqs[i]), float(levels[i])))
+            if len(marked) >= num_markers:
+                break
+    return marked
+
+
+def adj_siglvls(state, adj):
+    """_adj_siglvls K:400-411 on a ZeroSpanState / ScanState: (max, min, avg, cur) minus the saved baseline."""
+    if adj is None:
+        return state.max, state.min, state.avg, state.cur
+    return state.max - adj, state.min - adj, state.avg - adj, state.cur - adj
+
+
 # ---------------------------------------------------------------- A10 - A12 loop
 class ZeroSpanState:
     """The per-frame body of zero_span (K:464-484) without SDR / plotting."""

@@ -167,3 +167,121 @@ def test_u8_roundtrip_convention():
     y = orc.unpack_u8(b)
     assert np.max(np.abs(y - x)) <= (0.5 / 127.5) * np.sqrt(2) + 1e-12
     assert orc.unpack_u8(np.array([0, 255], dtype=np.uint8))[0] == complex(-1.0, 1.0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: reference-run vectors for the full-size scans, the dummy band, Save/AdjSigLvls and plot_highs
+# (tests/golden/make_golden_r2.py)
+def _regen_iq(g, count):
+    x = orc.synth_iq(count, int(g["seed"])).astype(np.complex64)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == str(g["iq_sha256"])
+    return x
+
+
+def _scan_state(g, **kw):
+    return orc.ScanState(int(g["fft_size"]), float(g["start_freq"]), float(g["end_freq"]), float(g["sampling_rate"]),
+                         float(g["gain"]), float(g["min_amp"]), int(g["xres"]), float(g["scan_non_overlap"]), **kw)
+
+
+@pytest.mark.parametrize("tag", ["fm_n16384", "quickfull_n64"])
+def test_full_size_scan_matches_reference(tag):
+    """BASELINE configs[2] (fmScan, 18 x 71 windows of 16384, kaiser) and configs[3]'s shape (quickFullScan,
+    1226 steps of 71 x 64), two passes each: sampled bins + decimated checksums of all four curves, the
+    waterfall rows of both passes."""
+    g = golden("scan_" + tag)
+    n, full, passes, steps = int(g["fft_size"]), int(g["full"]), int(g["passes"]), int(g["steps"])
+    assert steps == (18 if n == 16384 else 1226)
+    x = _regen_iq(g, full * steps * passes).reshape(passes, steps, full)
+    win = orc.window_table(str(g["window"]), n)
+    st = _scan_state(g)
+    assert st.total == int(g["total"])
+    for p in range(passes):
+        st.run_pass([orc.curscan(x[p, s], n, float(g["non_overlap"]), win, "AVG") for s in range(steps)])
+    cells = int(g["cells"])
+    for k in ("cur", "max", "min", "avg"):
+        y = getattr(st, k)
+        assert np.array_equal(y[g[k + "_idx"]], g[k + "_at_idx"]), k
+        assert np.array_equal(y.reshape(cells, -1).sum(axis=1), g[k + "_decim_sum"]), k
+        assert np.array_equal(y.reshape(cells, -1).max(axis=1), g[k + "_decim_max"]), k
+    assert np.array_equal(st.hm[:passes + 1], g["hm_rows"])
+    assert st.hm_index == int(g["hm_index"])
+
+
+def test_scan_dummy_band_matches_reference():
+    """A tune that fails (K:296-306) makes that band flat ones (K:637-639): steps 2 and 5 on passes 0 and 2."""
+    g = golden("scan_dummy_n512")
+    n, full, passes, steps = int(g["fft_size"]), int(g["full"]), int(g["passes"]), int(g["steps"])
+    ok = g["step_ok"]
+    x = _regen_iq(g, full * int(ok.sum())).reshape(-1, full)
+    win = orc.window_table(str(g["window"]), n)
+    st = _scan_state(g)
+    used = 0
+    for p in range(passes):
+        spectra = []
+        for s in range(steps):
+            if ok[p, s]:
+                spectra.append(orc.curscan(x[used], n, float(g["non_overlap"]), win, "AVG"))
+                used += 1
+            else:
+                spectra.append(None)
+        st.run_pass(spectra)
+    assert used == len(x)
+    for k in ("cur", "max", "min", "avg", "hm"):
+        assert np.array_equal(getattr(st, k), g[k]), k
+    assert st.hm_index == int(g["hm_index"])
+
+
+def test_adj_siglvls_zerospan_matches_reference():
+    """AdjSigLvls (K:400-411): the curves stay raw, the waterfall row, the Levels curves and the markers see
+    curve - Fft.Adj."""
+    g = golden("adj_zerospan_n512")
+    n, q, full, frames, xres = int(g["fft_size"]), float(g["non_overlap"]), int(g["full"]), int(g["frames"]), int(g["xres"])
+    x = _regen_iq(g, full * frames).reshape(frames, full)
+    adj = g["adj"]
+    st = orc.ZeroSpanState(n, xres, float(g["gain"]), adj=adj)
+    win = orc.window_table(str(g["window"]), n)
+    for fr in x:
+        st.push(orc.curscan(fr, n, q, win, "AVG"))
+    for k in ("cur", "max", "min", "avg", "hm"):
+        assert np.array_equal(getattr(st, k), g[k]), k
+    freqs = np.fft.fftshift(np.fft.fftfreq(n, 1 / 2.4e6) + (float(g["start_freq"]) + float(g["end_freq"])) / 2)
+    mode = str(g["compress"])
+    mx, mn, av, cu = orc.adj_siglvls(st, adj)
+    for name, y in (("lv_max", mx), ("lv_min", mn), ("lv_avg", av), ("lv_cur", cu)):
+        xs, ys = orc.data_plotcompress(freqs, y, xres, mode)
+        assert np.array_equal(xs, g["lv_x"]) and np.array_equal(ys, g[name]), name
+    xs, ys = orc.data_plotcompress(freqs, cu, xres, mode)       # the last curve plotted is Cur (K:499-504)
+    marks = orc.plot_highs(xs, ys, float(g["marker_delta"]), int(g["marker_count"]))
+    assert np.array_equal(np.array(marks), g["markers"])
+
+
+def test_adj_siglvls_scan_matches_reference():
+    g = golden("adj_scan_n256")
+    n, full, passes, steps, xres = int(g["fft_size"]), int(g["full"]), int(g["passes"]), int(g["steps"]), int(g["xres"])
+    x = _regen_iq(g, full * steps * passes).reshape(passes, steps, full)
+    adj = g["adj"]
+    st = _scan_state(g, adj=adj)
+    win = orc.window_table(str(g["window"]), n)
+    for p in range(passes):
+        st.run_pass([orc.curscan(x[p, s], n, float(g["non_overlap"]), win, "AVG") for s in range(steps)])
+    for k in ("cur", "max", "min", "avg", "hm"):
+        assert np.array_equal(getattr(st, k), g[k]), k
+    span = st.num_groups * float(g["sampling_rate"])
+    freqs = np.fft.fftshift(np.fft.fftfreq(st.total, 1 / span) + float(g["start_freq"]) + span / 2)   # K:609
+    mode = str(g["compress"])
+    mx, mn, av, cu = orc.adj_siglvls(st, adj)
+    for name, y in (("lv_max", mx), ("lv_min", mn), ("lv_avg", av), ("lv_cur", cu)):
+        xs, ys = orc.data_plotcompress(freqs, y, xres, mode)
+        assert np.array_equal(xs, g["lv_x"]) and np.array_equal(ys, g[name]), name
+    xs, ys = orc.data_plotcompress(freqs, cu, xres, mode)
+    marks = orc.plot_highs(xs, ys, float(g["marker_delta"]), int(g["marker_count"]))
+    assert np.array_equal(np.array(marks), g["markers"])
+
+
+def test_plot_highs_matches_reference():
+    g = golden("plot_highs")
+    for c, (delta, count) in enumerate(g["cases"]):
+        marks = orc.plot_highs(g["freqs%d" % c], g["levels%d" % c], float(delta), int(count))
+        assert np.array_equal(np.array(marks).reshape(-1, 2), g["marks%d" % c]), c
+    # case 4: 16 points, delta 0, 20 markers asked -> 15 marked: the lowest point is never visited (K:258)
+    assert len(g["marks4"]) == 15
