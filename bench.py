@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
-"""Headline benchmark: zeroSpan spectrum/waterfall hot path at BASELINE.json configs[1]
-(fftSize 4096, 50 % overlap, hanning, complex64 synthetic IQ), one process per GPU.
+"""Benchmark of the spectrum / waterfall hot path on MI355X, one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py                                  # headline: BASELINE configs[1], 1 GPU
+    python bench.py --config {2,3,4,5} --gpus N --steps K --warmup W
 
-One "step" = one pass of the whole hot path (IQ -> window -> FFT -> |X| -> fold -> dB -> Cur/Max/Min/Avg
-+ waterfall rows) over one HBM-resident batch of `--frames` capture blocks per GPU.  With N > 1 every rank
-owns a contiguous time chunk of the run (weak scaling: frames per GPU fixed), and the global Max/Min/Avg/Cur
-curves and the waterfall ring come from ONE RCCL all-gather + a local merge kernel per step (distributed.py).  Rank 0 prints ONE JSON line.
+--config picks the BASELINE.json configuration (1-based, as SURVEY.md section 8 numbers them):
+  2  zeroSpan, fftSize 4096, 50 % overlap, hanning, complex64 synthetic IQ      (headline, default)
+  3  fmScan 88-108 MHz, fftSize 16384 kaiser, 18 steps x 71 windows per pass, stitch + Max/Min/Avg + waterfall
+  4  quickFullScan shape (30e6-1.5e9, fftSize 64, 1226 steps per pass), band shard + RCCL gather of the spectra
+  5  zeroSpan, fftSize 65536, 75 % overlap (four-step path), time-chunk shard + RCCL merge of Max/Min/Avg
+
+One "step" = one pass of the whole hot path over one HBM-resident batch per GPU: `--frames` capture blocks
+(zeroSpan: IQ -> window -> FFT -> |X| -> fold -> dB -> Cur/Max/Min/Avg + waterfall rows) or `--passes` whole scan
+passes (every tuned band's block -> spectrum -> clip/dB, then stitch + Max/Min/Avg + waterfall row per pass).
+With N > 1 every rank owns a contiguous time chunk (zeroSpan) or a contiguous range of tuned bands (scan) and ONE
+RCCL all-gather per step carries what the ranks must share (distributed.py); weak scaling (work per GPU fixed).
+
+Launch: under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plainly as
+`python bench.py --gpus N`: the parent then starts N fresh rank processes itself (before it has touched the GPU),
+relays rank 0's JSON line and fails if any rank fails.  Rank 0 prints ONE JSON line on stdout.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,92 +35,220 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_FFT, FULL, Q, WINDOW, XRES, GAIN = 4096, 32768, 0.5, "hanning", 512, 19.1
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3   # vector fp32 peak, same guide (the FFT is not an MFMA shape)
+GAIN = 19.1
+FS = 2.4e6
+
+# name, geometry (SURVEY.md section 8 sizes), default batch per GPU per step
+CONFIGS = {
+    2: dict(workload="configs[1]: zeroSpan synthetic 2.4 MS/s complex64 IQ, fftSize=4096, 50% overlap, hanning",
+            metric="windowed FFTs/sec, fftSize=4096, 50% overlap, hanning (zeroSpan hot path incl. Max/Min/Avg/Cur + waterfall)",
+            mode="zerospan", n=4096, q=0.5, window="hanning", full=32768, xres=512, frames=65536),
+    3: dict(workload="configs[2]: scan 88-108 MHz stepped (fmScan), fftSize=16384 kaiser, min/max/avg + waterfall accumulate",
+            metric="windowed FFTs/sec, fmScan: fftSize=16384 kaiser, 18 steps x 71 windows per pass (scan hot path incl. stitch + Max/Min/Avg + waterfall)",
+            mode="scan", n=16384, q=0.1, window="kaiser", full=131072, xres=512, start=88e6, end=108e6, passes=256),
+    4: dict(workload="configs[3]: quickFullScan shape (30e6-1.5e9, fftSize=64), freq-band shard, RCCL gather of spectrum",
+            metric="windowed FFTs/sec, quickFullScan: fftSize=64, 1226 steps x 71 windows per pass (scan hot path incl. stitch + Max/Min/Avg + waterfall)",
+            mode="scan", n=64, q=0.1, window="ones", full=512, xres=64, start=30e6, end=1.5e9, passes=1024),
+    5: dict(workload="configs[4]: fftSize=65536, 75% overlap, synthetic IQ, time-chunk shard with RCCL merge of min/max/avg",
+            metric="windowed FFTs/sec, fftSize=65536, 75% overlap, hanning (zeroSpan hot path incl. Max/Min/Avg/Cur + waterfall)",
+            mode="zerospan", n=65536, q=0.25, window="hanning", full=524288, xres=512, frames=2048),
+}
 
 
-def algorithmic_bytes_per_frame(sample_bytes, hm_w):
-    """one read of every IQ sample, one write of the Cur curve, one waterfall row."""
-    return FULL * sample_bytes + 4 * N_FFT + 4 * hm_w
+def _oracle():
+    """oracle/ is test infrastructure: bench.py uses it for the synthetic source and as the timed CPU
+    baseline leg only -- nothing of it runs inside the GPU-timed region."""
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import ksa_oracle
+    return ksa_oracle
 
 
-def cpu_baseline(seconds=12.0):
-    """The float64 numpy oracle (a port of the reference's numpy path) on one host core, on a bounded
-    sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ksa_oracle as orc
-    win = orc.window_table(WINDOW, N_FFT)
-    nfr = 64
-    x = orc.synth_iq(FULL * nfr, 20201226 + 2).astype(np.complex64).reshape(nfr, FULL)
-    st = orc.ZeroSpanState(N_FFT, XRES, GAIN)
-    nwin = len(orc.window_starts(FULL, N_FFT, Q))
-    done = 0
-    t0 = time.perf_counter()
-    while True:
-        for fr in x:
-            st.push(orc.curscan(fr, N_FFT, Q, win, "AVG"))
-        done += nfr
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            break
-    return {"value": done * nwin / dt, "unit": "FFT/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of 32768 complex samples (%d FFTs) in %.1f s, numpy float64, 1 thread of %d usable"
-                      % (done, done * nwin, dt, len(os.sched_getaffinity(0)))}
+def scan_geometry(cfg):
+    orc = _oracle()
+    end, _ = orc.fixup_scan_range(cfg["start"], cfg["end"], FS)
+    steps = len(orc.scan_steps(cfg["start"], end, FS, 0.5))
+    groups = int((end - cfg["start"]) / FS)
+    return end, steps, groups * cfg["n"]
 
 
-def _cpu_worker(args):
-    seconds, seed = args
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ksa_oracle as orc
-    win = orc.window_table(WINDOW, N_FFT)
-    x = orc.synth_iq(FULL * 16, seed).astype(np.complex64).reshape(16, FULL)
-    st = orc.ZeroSpanState(N_FFT, XRES, GAIN)
-    done, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for fr in x:
-            st.push(orc.curscan(fr, N_FFT, Q, win, "AVG"))
-        done += 16
-    return done, time.perf_counter() - t0
+def algorithmic_bytes(cfg, sample_bytes, nwin):
+    """SURVEY.md 8(d), bytes per unit (frame or tuned band): one read of every IQ sample + one write of the unit's
+    spectrum (+ one waterfall row per frame in zeroSpan; per pass in scan, amortised over its steps)."""
+    b = cfg["full"] * sample_bytes + 4 * cfg["n"]
+    if cfg["mode"] == "zerospan":
+        b += 4 * min(cfg["n"], cfg["xres"])
+    return b
 
 
-def cpu_baseline_multicore(seconds=6.0, max_workers=16):
-    """the same numpy port on independent frames, one plain child process per usable core (capped
-    at the box's CPU share) -- the non-target multi-core figure.  Children never touch the GPU; any failure or
-    timeout just drops the figure."""
-    import subprocess
+def algorithmic_flops_per_fft(n):
+    """5 N log2 N butterflies + ~12 N for window, magnitude, fold and dB."""
+    return 5.0 * n * np.log2(n) + 12.0 * n
+
+
+# ------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_unit_fn(cfg):
+    """One unit of the workload on the float64 numpy port (the oracle): a zeroSpan frame incl. the accumulate and
+    the waterfall row, or one tuned band of a scan incl. clip + dB (the per-pass stitch is timed with it)."""
+    orc = _oracle()
+    n, q, full = cfg["n"], cfg["q"], cfg["full"]
+    win = orc.window_table(cfg["window"], n)
+    if cfg["mode"] == "zerospan":
+        st = orc.ZeroSpanState(n, cfg["xres"], GAIN)
+        return lambda x: st.push(orc.curscan(x, n, q, win, "AVG")), None
+    end, steps, _ = scan_geometry(cfg)
+    state = orc.ScanState(n, cfg["start"], end, FS, GAIN, (1 / 256) * 0.00001, cfg["xres"])
+    return (lambda x: orc.curscan(x, n, q, win, "AVG")), (state, steps)
+
+
+def _cpu_rounds(cfg, seed, rounds, seconds):
+    """`rounds` measurements of >= `seconds` each; returns [(units, dt)]."""
+    orc = _oracle()
+    full = cfg["full"]
+    distinct = max(2, min(32, (8 << 20) // (full * 8)))
+    x = orc.synth_iq(full * distinct, seed).astype(np.complex64).reshape(distinct, full)
+    unit, scan = _cpu_unit_fn(cfg)
+    out = []
+    for _ in range(rounds):
+        done, t0 = 0, time.perf_counter()
+        pending = []
+        while True:
+            r = unit(x[done % distinct])
+            done += 1
+            if scan is not None:
+                pending.append(r)
+                if len(pending) == scan[1]:        # a whole pass captured: stitch + accumulate (K:621-668)
+                    scan[0].run_pass(pending)
+                    pending = []
+            if (done & 3) == 0 and time.perf_counter() - t0 >= seconds:
+                break
+        out.append((done, time.perf_counter() - t0))
+    return out
+
+
+def cpu_baseline(cfg, nwin, seconds=3.0, rounds=5):
+    """the numpy float64 port on ONE host core, median of `rounds` measurements of >= `seconds`."""
+    res = _cpu_rounds(cfg, 20201226 + 2, rounds, seconds)
+    rates = sorted(u * nwin / dt for u, dt in res)
+    unit = "frames" if cfg["mode"] == "zerospan" else "tuned bands"
+    return {"value": rates[len(rates) // 2], "unit": "FFT/s", "cores": 1, "kind": "port",
+            "sample": "median of %d runs of >= %.1f s (%d..%d %s of %d complex samples each, %d FFTs of %d per unit), numpy float64, "
+                      "1 thread of %d usable" % (rounds, seconds, min(u for u, _ in res), max(u for u, _ in res), unit,
+                                                 cfg["full"], nwin, cfg["n"], len(os.sched_getaffinity(0)))}
+
+
+def cpu_baseline_multicore(config_id, nwin, seconds=3.0, rounds=5, max_workers=16):
+    """the same port on independent units, one plain child process per usable core -- capped at 16,
+    the CPU share (and process budget) a one-GPU box grants -- the non-target multi-core figure.  Children never
+    touch the GPU; any failure or timeout just drops the figure."""
     workers = max(1, min(max_workers, len(os.sched_getaffinity(0))))
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds), str(100 + i)],
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(workers)]
-    res = []
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(config_id), str(seconds),
+                               str(rounds), str(100 + i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+             for i in range(workers)]
+    per_worker = []
     try:
         for pr in procs:
-            out, _ = pr.communicate(timeout=seconds + 60)
-            done, dt = out.strip().split()[-2:]
-            res.append((int(done), float(dt)))
+            out, _ = pr.communicate(timeout=seconds * rounds + 120)
+            per_worker.append(json.loads(out.strip().splitlines()[-1]))
     except Exception:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
         return None
-    frames = sum(r[0] for r in res)
-    dt = max(r[1] for r in res)
-    return {"value": frames * 15 / dt, "unit": "FFT/s", "cores": workers, "kind": "port",
-            "sample": "%d frames over %d processes in %.1f s, numpy float64" % (frames, workers, dt)}
+    rates = sorted(sum(w[r][0] for w in per_worker) * nwin / max(w[r][1] for w in per_worker) for r in range(rounds))
+    return {"value": rates[len(rates) // 2], "unit": "FFT/s", "cores": workers, "kind": "port",
+            "sample": "median of %d runs of >= %.1f s over %d processes (of %d usable cores; 16 = the box's CPU share), numpy float64"
+                      % (rounds, seconds, workers, len(os.sched_getaffinity(0)))}
 
 
+# ------------------------------------------------------------------------------------------- self launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N fresh rank processes (this parent has not
+    initialised the GPU and never does), relay rank 0's JSON line, fail if any rank fails."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), KSA_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad:                              # one rank died: the others would wait in a collective for ever
+            rc = bad[0].returncode
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()            # the exact PIDs started above
+            break
+        time.sleep(0.2)
+    out = procs[0].communicate()[0]
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=60)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    rc = rc or next((p.returncode for p in procs if p.returncode), 0)
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    if rc or not lines:
+        sys.stderr.write("bench.py: rank processes failed (rc %s)\n" % rc)
+        raise SystemExit(rc or 1)
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+
+
+def csrc_sha256():
+    """Hash of the kernel sources the library is built from: stamps profiles/pmc_traffic.json so that counter
+    traffic measured on an older kernel is never reported for a newer one."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "prgs-sdr-kspecanal_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(key):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+        ent = rec.get("entries", {}).get(key)
+        if ent and ent.get("csrc_sha256") == csrc_sha256():
+            return ent["hbm_bytes_per_launch"], ent.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------- the bench
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=65536, help="capture blocks per GPU per step (65536 = 16 GiB of complex64 resident in HBM)")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=2, help="BASELINE.json configuration (1-based)")
+    ap.add_argument("--frames", type=int, default=None, help="zeroSpan configs: capture blocks per GPU per step")
+    ap.add_argument("--passes", type=int, default=None, help="scan configs: whole passes per step")
     ap.add_argument("--fmt", choices=("c64", "u8"), default="c64")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="length of each of the 5 CPU measurements")
     ap.add_argument("--force-collective", action="store_true",
-                    help="N=1 only: run the multi-GPU merge path (all-gather + merge kernel) on a one-rank group, to price its fixed cost")
+                    help="N=1, zeroSpan only: run the multi-GPU merge path on a one-rank group, to price its fixed cost")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     # stdout carries exactly ONE line (the JSON): native libraries that print to fd 1 (RCCL's version banner
     # does) are sent to stderr for the whole run, the JSON goes to the saved descriptor at the end
@@ -120,12 +260,14 @@ def main():
     import torch.distributed as dist
     ksa = importlib.import_module("prgs-sdr-kspecanal_amd")
     ksa_dist = importlib.import_module("prgs-sdr-kspecanal_amd.distributed")
+    orc = _oracle()   # synthetic source only on this leg
 
+    cfg = dict(CONFIGS[args.config])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     # one rank per GPU; KSA_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the launch path
     backend = os.environ.get("KSA_BENCH_BACKEND", "nccl")
     local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
@@ -137,33 +279,56 @@ def main():
             dist.init_process_group(backend)
     elif args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group(backend, rank=0, world_size=1, device_id=torch.device("cuda", local) if backend == "nccl" else None)
 
-    frames = args.frames
+    n, full, q = cfg["n"], cfg["full"], cfg["q"]
     sb = 8 if args.fmt == "c64" else 2
     fmt = ksa.FMT_C64 if args.fmt == "c64" else ksa.FMT_U8
-    # synthetic input: 256 distinct frames generated on the host, tiled in HBM (content does not affect timing)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ksa_oracle as orc   # synthetic source only; nothing of the oracle is timed on the GPU leg
-    distinct = min(frames, 256)
-    host = orc.synth_iq(FULL * distinct, 20201226 + 2 + rank).astype(np.complex64)
-    if args.fmt == "c64":
-        tile = torch.view_as_real(torch.from_numpy(host)).reshape(distinct, FULL, 2).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def resident_iq(units):
+        """`units` capture blocks in HBM, tiled from <= 64 MiB of distinct host-generated blocks (content does not
+        affect timing; H2D is outside the timed region)."""
+        distinct = max(1, min(units, 256, (64 << 20) // (full * 8)))
+        host = orc.synth_iq(full * distinct, 20201226 + args.config + rank).astype(np.complex64)
+        if args.fmt == "c64":
+            tile = torch.view_as_real(torch.from_numpy(host)).reshape(distinct, full, 2).cuda()
+        else:
+            tile = torch.from_numpy(orc.quantize_u8(host * 0.8)).reshape(distinct, full * 2).cuda()
+        reps = (units + distinct - 1) // distinct
+        return tile.repeat(reps, *([1] * (tile.dim() - 1)))[:units].contiguous()
+
+    if cfg["mode"] == "zerospan":
+        frames = args.frames or cfg["frames"]
+        units_per_step = frames                       # per rank
+        iq = resident_iq(frames)
+        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=cfg["window"], gain=GAIN, xres=cfg["xres"],
+                                 max_frames=frames, device=local, stream=stream)
+        cur_db = torch.empty((frames, n), dtype=torch.float32, device="cuda")
+        hm_rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
+        run = ksa_dist.ShardedZeroSpan(eng, rank, world, always_collective=args.force_collective)
+        step = lambda: run.step(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
+        sharding = "time-chunk"
+        collective = ("RCCL: 1 all-gather of [4N + 128W] floats per rank per step over %d ranks, merged by ksa_merge_gathered_dev"
+                      % world) if world > 1 else "none"
+        batch = {"frames_per_gpu_per_step": frames}
     else:
-        tile = torch.from_numpy(orc.quantize_u8(host * 0.8)).reshape(distinct, FULL * 2).cuda()
-    reps = (frames + distinct - 1) // distinct
-    iq = tile.repeat(reps, *([1] * (tile.dim() - 1)))[:frames].contiguous()
-    del tile
-
-    eng = ksa.SpectrumEngine(N_FFT, full_size=FULL, non_overlap=Q, window=WINDOW, gain=GAIN, xres=XRES,
-                             max_frames=frames, device=local, stream=torch.cuda.current_stream().cuda_stream)
-    cur_db = torch.empty((frames, N_FFT), dtype=torch.float32, device="cuda")
-    hm_rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
-    run = ksa_dist.ShardedZeroSpan(eng, rank, world, always_collective=args.force_collective)
-
-    def step():
-        run.step(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
+        passes = args.passes or cfg["passes"]
+        end, steps, total = scan_geometry(cfg)
+        lo, hi = ksa_dist.step_range(steps, rank, world)
+        mine = hi - lo
+        units_per_step = passes * mine                # tuned bands this rank transforms per step
+        iq = resident_iq(max(1, passes * mine))
+        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=cfg["window"], gain=GAIN, xres=cfg["xres"],
+                                 max_frames=max(1, passes * mine), device=local, scan_total_entries=total,
+                                 scan_non_overlap=0.5, stream=stream)
+        run = ksa_dist.ShardedScan(eng, rank, world)
+        step = lambda: run.run_passes(iq, fmt, steps, passes)
+        sharding = "freq-band"
+        collective = ("RCCL: 1 all-gather of the per-band spectra [passes][steps][N] per step over %d ranks, stitched on every rank"
+                      % world) if world > 1 else "none"
+        batch = {"passes_per_step": passes, "steps_per_pass": steps, "bands_on_rank0": mine, "total_entries": total}
 
     def fence():
         torch.cuda.synchronize()
@@ -190,41 +355,46 @@ def main():
 
     if rank == 0:
         nwin = eng.num_windows
-        total_frames = frames * world * args.steps
-        ffts_per_s = total_frames * nwin / dt
+        if cfg["mode"] == "zerospan":
+            units_all = units_per_step * world * args.steps
+        else:
+            units_all = (args.passes or cfg["passes"]) * steps * args.steps
+        ffts_per_s = units_all * nwin / dt
         info = eng.kernel_info()
-        bpf = algorithmic_bytes_per_frame(sb, eng.hm_width)
+        bpu = algorithmic_bytes(cfg, sb, nwin)
         avg_kernel_s = kern_ms / 1e3 / max(1, launches)
-        achieved = frames * bpf / avg_kernel_s / 1e9
+        alg_bytes = units_per_step * bpu
+        achieved = alg_bytes / avg_kernel_s / 1e9
+        tflops = units_per_step * nwin * algorithmic_flops_per_fft(n) / avg_kernel_s / 1e12
+        step_s = dt / args.steps
+        if info["path"] == 1:
+            kernel = "ksa four-step path (column + row kernels, N = N1*N2 through HBM/L2 scratch)"
+        else:
+            kernel = "ksa::spectrum_kernel<%d,%s>" % (n, args.fmt)
+        key = "%d:%s:%d" % (args.config, args.fmt, units_per_step)
+        traffic, traffic_src = pmc_traffic(key)
         out = {
-            "metric": "windowed FFTs/sec, fftSize=4096, 50% overlap, hanning (zeroSpan hot path incl. Max/Min/Avg/Cur + waterfall)",
-            "value": ffts_per_s, "unit": "FFT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": cfg["metric"], "value": ffts_per_s, "unit": "FFT/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "msamples_per_s": total_frames * FULL / dt / 1e6,
-            "config": {"workload": "configs[1]: zeroSpan synthetic 2.4 MS/s IQ, fftSize=4096, 50% overlap, hanning",
-                       "input": "complex64" if args.fmt == "c64" else "uint8", "frames_per_gpu_per_step": frames,
-                       "samples_per_frame": FULL, "windows_per_frame": nwin, "sharding": "time-chunk",
-                       "collective": "RCCL: 1 all-gather of [4N + 128W] floats per rank per step, merged by ksa_merge_gathered_dev" if world > 1 else "none"},
+            "msamples_per_s": units_all * full / dt / 1e6,
+            "config": dict({"workload": cfg["workload"], "baseline_config": args.config,
+                            "input": "complex64" if args.fmt == "c64" else "uint8", "samples_per_unit": full,
+                            "windows_per_unit": nwin, "sharding": sharding, "collective": collective}, **batch),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "ksa::spectrum_kernel<4096,%s>" % ("c64" if args.fmt == "c64" else "u8"),
-                         "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
-                         "algorithmic_bytes_per_launch": frames * bpf,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_unit": bpu,
+                         # the whole step (spectrum stage + accumulate/stitch + collective) against the same bytes
+                         "frac_step": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                         # at 75-90 % overlap the path is far from HBM-bound: fp32 vector fraction next to it
+                         "tflops": tflops, "flop_peak": FP32_PEAK_TFLOPS, "flop_frac": tflops / FP32_PEAK_TFLOPS,
                          "threads": info["threads"], "lds_bytes": info["lds_bytes"], "vgprs": info["vgprs"],
-                         "grid": min(frames, info["grid"])},
+                         "grid": info["grid"]},
         }
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("frames") == frames and rec.get("fmt") == args.fmt:
-                    out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-            except Exception:
-                pass
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-            multi = cpu_baseline_multicore()
+            out["cpu_baseline"] = cpu_baseline(cfg, nwin, args.cpu_seconds)
+            multi = cpu_baseline_multicore(args.config, nwin, args.cpu_seconds)
             if multi is not None:
                 out["cpu_baseline_multicore"] = multi
         sys.stdout.flush()
@@ -236,7 +406,8 @@ def main():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-worker":     # child of cpu_baseline_multicore
-        print(*_cpu_worker((float(sys.argv[2]), int(sys.argv[3]))))
+    if len(sys.argv) == 6 and sys.argv[1] == "--cpu-worker":     # child of cpu_baseline_multicore
+        cid, secs, rnds, seed = int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+        print(json.dumps(_cpu_rounds(dict(CONFIGS[cid]), seed, rnds, secs)))
     else:
         main()

@@ -131,6 +131,14 @@ int ksa_scan_pass_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t fr
                       int32_t nsteps, const uint8_t* step_ok);
 /* Same, from per-step dB spectra already on the device ([nsteps][N], KSA_OUT_DB_CLIP units). */
 int ksa_scan_stitch_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps);
+/* A batch of `npasses` captured passes resident in HBM (block of pass p, step s at iq_dev + (p*nsteps + s)*
+ * frame_stride): the spectrum stage runs once over all npasses*nsteps blocks (<= max_frames), then every element
+ * of the stitched range walks the passes in order -- the same state as npasses ksa_scan_pass_dev calls, and the
+ * last 128 passes' waterfall rows.  step_ok: host[npasses*nsteps] or NULL. */
+int ksa_scan_passes_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride,
+                        int32_t nsteps, int32_t npasses, const uint8_t* step_ok);
+int ksa_scan_stitch_passes_dev(ksa_engine* e, const float* step_db_dev /* [npasses][nsteps][N] */,
+                               int32_t nsteps, int32_t npasses);
 int ksa_scan_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg, float* hm,
                         int32_t* hm_index, int64_t* passes);
 int ksa_scan_state_dev(ksa_engine* e, float** state_dev, float** hm_ring_dev);
@@ -143,6 +151,14 @@ int ksa_scan_set_base_is_raw(ksa_engine* e, int32_t on);
 /* The four curves (cur, max, min, avg; minus Fft.Adj if set, K:400-411) reduced on the device to `cells`
  * groups with pltCompress AVG (0) / MAX (1) / MIN (2): out_host[4][cells].  scan != 0 reads the scan state. */
 int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, float* out_host);
+
+/* Peak markers of plot_highs (K:243-272) chosen on the device from the same decimated curve: walk `curve`
+ * (0 cur, 1 max, 2 min, 3 avg; reduced to `cells` groups with `mode` as above) from its highest level down and
+ * mark a cell unless an already marked one is closer than min_sep_cells (= pltHighsDelta4Marking * (x[-1]-x[0]) /
+ * cell width, K:249-250, K:261-262), until `count` (<= 64) are marked (K:268-269).  As in the reference NaN sorts
+ * above +inf and the lowest point is never visited (K:258).  idx_host / lvl_host: [count]; *found = cells marked. */
+int ksa_read_highs(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, int32_t curve, double min_sep_cells,
+                   int32_t count, int32_t* idx_host, float* lvl_host, int32_t* found);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event timing of the spectrum kernel on the engine's stream: enable, run, then read the sum

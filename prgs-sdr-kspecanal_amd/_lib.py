@@ -61,11 +61,14 @@ SIGNATURES = {
     "ksa_set_hm_index": (C.c_int, [_P, _I32]),
     "ksa_scan_pass_dev": (C.c_int, [_P, _P, _I32, _I64, _I32, _P]),
     "ksa_scan_stitch_dev": (C.c_int, [_P, _P, _I32]),
+    "ksa_scan_passes_dev": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
+    "ksa_scan_stitch_passes_dev": (C.c_int, [_P, _P, _I32, _I32]),
     "ksa_scan_read_state": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(_I32), C.POINTER(_I64)]),
     "ksa_scan_state_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "ksa_scan_reset": (C.c_int, [_P]),
     "ksa_scan_set_base_is_raw": (C.c_int, [_P, _I32]),
     "ksa_read_levels": (C.c_int, [_P, _I32, _I32, _I32, _P]),
+    "ksa_read_highs": (C.c_int, [_P, _I32, _I32, _I32, _I32, C.c_double, _I32, _P, _P, C.POINTER(_I32)]),
     "ksa_prof_enable": (C.c_int, [_P, _I32]),
     "ksa_prof_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "ksa_kernel_info": (C.c_int, [_P] + [C.POINTER(_I32)] * 5),

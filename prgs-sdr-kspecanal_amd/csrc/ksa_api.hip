@@ -79,7 +79,9 @@ struct ksa_engine {
   float* d_hm = nullptr;        // [128][hm_width]   (= d_xchg + 4N)
   float* d_scan_state = nullptr;  // [4][total]
   float* d_scan_hm = nullptr;     // [128][scan_hm_width]
+  float* d_scan_avg_rows = nullptr;  // [128][total] Fft.Avg after each of a batch's last passes (multi-pass stitch)
   float* d_levels = nullptr;      // [4][cells] plot-side decimation scratch
+  int* d_highs = nullptr;         // peak markers: [HIGHS_MAX] cell | [HIGHS_MAX] level (float bits) | found
   float* d_parts = nullptr;       // [capacity][N] partial folds of the window-split (latency) mode
   int levels_cap = 0;
   ksa::FourStep four;           // N > 16384
@@ -88,6 +90,7 @@ struct ksa_engine {
   int hm_index = 0;
   int pending_frames = 0;       // frames of the last uncommitted batch
   int b_max = 1, b_min = 1, b_avg = 1;
+  int has_max = 0, has_min = 0, has_avg = 0;   // the curve holds frames already (seeded by copy otherwise, K:133-134)
   int scan_base_is_raw = 0;
   long long scan_passes = 0;
   int scan_hm_index = 0;
@@ -297,7 +300,7 @@ int run_accumulate(ksa_engine* e, const float* db, int nframes, long long first_
   a.nframes = nframes;
   a.first_index = first_index;
   a.total_frames = total;
-  a.has_prev = e->frames_seen > 0;
+  a.has_prev = e->has_avg;
   int chunks = std::min(e->max_chunks, std::max(1, nframes / 64));
   a.chunk = (nframes + chunks - 1) / chunks;
   chunks = (nframes + a.chunk - 1) / a.chunk;
@@ -316,8 +319,11 @@ int do_commit(ksa_engine* e, long long total, int local_frames) {
   const int n = e->cfg.fft_size;
   const int tb = 256, gx = (n + tb - 1) / tb;
   hipLaunchKernelGGL(ksa::commit_kernel, dim3(gx), dim3(tb), 0, e->stream, e->d_partial, e->d_state, n,
-                     e->frames_seen > 0 ? 1 : 0, total, e->b_max, e->b_min, e->b_avg);
+                     e->has_max, e->has_min, e->has_avg, total, e->b_max, e->b_min, e->b_avg);
   HIP_OK(hipGetLastError());
+  e->has_max |= e->b_max;
+  e->has_min |= e->b_min;
+  e->has_avg |= e->b_avg;
   e->frames_seen += total;
   e->hm_index = (int)((e->hm_index + local_frames) % KSA_HM_ROWS);
   e->pending_frames = 0;
@@ -495,7 +501,7 @@ void ksa_destroy(ksa_engine* e) {
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   void* ptrs[] = {e->d_starts, e->d_start_last, e->d_window, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
                   e->d_iq_stage, e->d_frames, e->d_part, e->d_xchg, e->d_state, e->d_scan_state, e->d_scan_hm,
-                  e->d_levels, e->d_parts};
+                  e->d_levels, e->d_parts, e->d_highs, e->d_scan_avg_rows};
   for (void* p : ptrs) if (p) hipFree(p);
   ksa::fourstep_destroy(e->four);
   delete e;
@@ -659,6 +665,7 @@ int ksa_reset_state(ksa_engine* e) {
   HIP_OK(hipMemsetAsync(e->d_state, 0, (size_t)4 * e->cfg.fft_size * 4, e->stream));
   if (e->d_hm) HIP_OK(hipMemsetAsync(e->d_hm, 0, (size_t)KSA_HM_ROWS * e->cfg.hm_width * 4, e->stream));  // np.zeros K:456
   e->frames_seen = 0;
+  e->has_max = e->has_min = e->has_avg = 0;
   e->hm_index = 0;
   e->pending_frames = 0;
   return 0;
@@ -696,11 +703,11 @@ int ksa_set_hm_index(ksa_engine* e, int32_t hm_index) {
   return 0;
 }
 
-int ksa_scan_stitch_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps) {
+static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int npasses) {
   if (!e || !step_db_dev) return fail("null argument");
   const ksa_config& c = e->cfg;
   if (!c.scan_total_entries) return fail("engine was created without scan geometry");
-  if (nsteps < 1) return fail("nsteps must be >= 1");
+  if (nsteps < 1 || npasses < 1) return fail("nsteps and npasses must be >= 1");
   HIP_OK(hipSetDevice(c.device));
   ksa::StitchParams s{};
   s.step_db = step_db_dev;
@@ -713,31 +720,62 @@ int ksa_scan_stitch_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps)
   s.b_max = e->b_max;
   s.b_min = e->b_min;
   s.base_is_raw = e->scan_base_is_raw;
+  s.npasses = npasses;
+  const int rows = std::min(npasses, KSA_HM_ROWS);       // only the last 128 passes of a batch reach the ring
+  if (npasses > 1) {
+    // Fft.Avg after each of those passes: the waterfall row of a pass is built from it (K:696-697)
+    if (!e->d_scan_avg_rows)
+      HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_scan_avg_rows), (size_t)KSA_HM_ROWS * s.total * 4));
+    s.avg_rows = e->d_scan_avg_rows;
+    s.avg_row0 = npasses - rows;
+  }
   const int tb = 256;
   hipLaunchKernelGGL(ksa::scan_stitch_kernel, dim3((s.total + tb - 1) / tb), dim3(tb), 0, e->stream, s);
   const int g = c.scan_total_entries / c.scan_hm_width;
-  hipLaunchKernelGGL(ksa::rowmax_kernel, dim3((c.scan_hm_width + tb - 1) / tb), dim3(tb), 0, e->stream,
-                     e->d_scan_state + (size_t)3 * s.total, e->d_scan_adj, c.scan_hm_width, g,
-                     e->d_scan_hm + (size_t)e->scan_hm_index * c.scan_hm_width);
+  if (npasses == 1) {
+    hipLaunchKernelGGL(ksa::rowmax_kernel, dim3((c.scan_hm_width + tb - 1) / tb), dim3(tb), 0, e->stream,
+                       e->d_scan_state + (size_t)3 * s.total, e->d_scan_adj, c.scan_hm_width, g,
+                       e->d_scan_hm + (size_t)e->scan_hm_index * c.scan_hm_width);
+  } else {
+    hipLaunchKernelGGL(ksa::rowmax_rows_kernel, dim3((c.scan_hm_width + tb - 1) / tb, rows), dim3(tb), 0, e->stream,
+                       e->d_scan_avg_rows, e->d_scan_adj, c.scan_hm_width, g, e->d_scan_hm,
+                       (e->scan_hm_index + s.avg_row0) % KSA_HM_ROWS);
+  }
   HIP_OK(hipGetLastError());
-  e->scan_passes += 1;
-  e->scan_hm_index = (e->scan_hm_index + 1) % KSA_HM_ROWS;  // K:732
+  e->scan_passes += npasses;
+  e->scan_hm_index = (e->scan_hm_index + npasses) % KSA_HM_ROWS;  // K:732, once per pass
   return 0;
+}
+
+int ksa_scan_stitch_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps) {
+  return scan_stitch(e, step_db_dev, nsteps, 1);
+}
+
+int ksa_scan_stitch_passes_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps, int32_t npasses) {
+  return scan_stitch(e, step_db_dev, nsteps, npasses);
+}
+
+int ksa_scan_passes_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride, int32_t nsteps,
+                        int32_t npasses, const uint8_t* step_ok) {
+  if (!e || !iq_dev) return fail("null argument");
+  if (!e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
+  if (nsteps < 1 || npasses < 1) return fail("nsteps and npasses must be >= 1");
+  const long long frames = (long long)nsteps * npasses;
+  if (frames > e->cfg.max_frames) return fail("%d passes x %d steps exceed max_frames %d", npasses, nsteps, e->cfg.max_frames);
+  HIP_OK(hipSetDevice(e->cfg.device));
+  if (run_spectrum(e, iq_dev, fmt, frame_stride, (int)frames, KSA_OUT_DB_CLIP, e->d_frames, false, nullptr)) return 1;
+  if (step_ok) {
+    // dummy band: ones(fftSize) through Clip2MinAmp + LogNoGain (K:637-641)
+    const float v = (float)(10.0 * std::log10(std::max(1.0, (double)e->cfg.min_amp)) - (double)e->cfg.gain);
+    for (long long s = 0; s < frames; ++s)
+      if (!step_ok[s] && fill(e, e->d_frames + (size_t)s * e->cfg.fft_size, e->cfg.fft_size, v)) return 1;
+  }
+  return scan_stitch(e, e->d_frames, nsteps, npasses);
 }
 
 int ksa_scan_pass_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride, int32_t nsteps,
                       const uint8_t* step_ok) {
-  if (!e || !iq_dev) return fail("null argument");
-  if (!e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
-  HIP_OK(hipSetDevice(e->cfg.device));
-  if (run_spectrum(e, iq_dev, fmt, frame_stride, nsteps, KSA_OUT_DB_CLIP, e->d_frames, false, nullptr)) return 1;
-  if (step_ok) {
-    // dummy band: ones(fftSize) through Clip2MinAmp + LogNoGain (K:637-641)
-    const float v = (float)(10.0 * std::log10(std::max(1.0, (double)e->cfg.min_amp)) - (double)e->cfg.gain);
-    for (int s = 0; s < nsteps; ++s)
-      if (!step_ok[s] && fill(e, e->d_frames + (size_t)s * e->cfg.fft_size, e->cfg.fft_size, v)) return 1;
-  }
-  return ksa_scan_stitch_dev(e, e->d_frames, nsteps);
+  return ksa_scan_passes_dev(e, iq_dev, fmt, frame_stride, nsteps, 1, step_ok);
 }
 
 int ksa_scan_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg, float* hm, int32_t* hm_index,
@@ -775,8 +813,7 @@ int ksa_scan_reset(ksa_engine* e) {
   return scan_reset(e);
 }
 
-int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, float* out_host) {
-  if (!e || !out_host) return fail("null argument");
+static int levels_to_scratch(ksa_engine* e, int scan, int mode, int cells) {
   if (mode < 0 || mode > 2) return fail("levels mode %d (0 AVG, 1 MAX, 2 MIN)", mode);
   const int n = scan ? e->cfg.scan_total_entries : e->cfg.fft_size;
   if (scan && !n) return fail("engine was created without scan geometry");
@@ -792,8 +829,43 @@ int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, fl
   hipLaunchKernelGGL(ksa::levels_kernel, dim3((cells + tb - 1) / tb, 4), dim3(tb), 0, e->stream,
                      scan ? e->d_scan_state : e->d_state, scan ? e->d_scan_adj : e->d_adj, n, cells, mode, e->d_levels);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, float* out_host) {
+  if (!e || !out_host) return fail("null argument");
+  if (levels_to_scratch(e, scan, mode, cells)) return 1;
   HIP_OK(hipMemcpyAsync(out_host, e->d_levels, (size_t)4 * cells * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_OK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int ksa_read_highs(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, int32_t curve, double min_sep_cells,
+                   int32_t count, int32_t* idx_host, float* lvl_host, int32_t* found) {
+  if (!e || !idx_host || !lvl_host || !found) return fail("null argument");
+  if (curve < 0 || curve > 3) return fail("curve %d (0 cur, 1 max, 2 min, 3 avg)", curve);
+  if (count < 1 || count > ksa::HIGHS_MAX) return fail("marker count %d outside 1..%d", count, ksa::HIGHS_MAX);
+  if (!(min_sep_cells >= 0.0)) return fail("min_sep_cells must be >= 0");
+  if (levels_to_scratch(e, scan, mode, cells)) return 1;
+  if (!e->d_highs) HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_highs), (2 * ksa::HIGHS_MAX + 1) * 4));
+  ksa::HighsParams h{};
+  h.lv = e->d_levels + (size_t)curve * cells;
+  h.cells = cells;
+  h.min_sep = min_sep_cells;
+  h.count = count;
+  h.idx = e->d_highs;
+  h.lvl = reinterpret_cast<float*>(e->d_highs + ksa::HIGHS_MAX);
+  h.found = e->d_highs + 2 * ksa::HIGHS_MAX;
+  hipLaunchKernelGGL(ksa::highs_kernel, dim3(1), dim3(1024), 0, e->stream, h);
+  HIP_OK(hipGetLastError());
+  int host[2 * ksa::HIGHS_MAX + 1];
+  HIP_OK(hipMemcpyAsync(host, e->d_highs, sizeof host, hipMemcpyDeviceToHost, e->stream));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  *found = host[2 * ksa::HIGHS_MAX];
+  for (int i = 0; i < *found; ++i) {
+    idx_host[i] = host[i];
+    memcpy(&lvl_host[i], &host[ksa::HIGHS_MAX + i], 4);
+  }
   return 0;
 }
 

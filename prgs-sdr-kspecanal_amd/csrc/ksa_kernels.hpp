@@ -541,7 +541,7 @@ struct AccParams {
   const float* db;   // [nframes][N]
   int n, nframes;
   long long first_index, total_frames;  // position of this batch in the logical run
-  int has_prev;      // state already holds frames
+  int has_prev;      // Fft.Avg already holds frames (it is seeded by copy otherwise: data_cumu(None), K:133-134)
   int chunk;         // frames per partial
   float* part;       // [chunks][3][N] : max, min, sum
 };
@@ -645,18 +645,20 @@ __global__ void merge_gathered_kernel(const float* g, int world, long long strid
   }
 }
 
-// state layout: [cur | max | min | avg]
-__global__ void commit_kernel(const float* partial, float* state, int n, int has_prev,
+// state layout: [cur | max | min | avg].  has_max / has_min / has_avg: that curve already holds frames; a curve
+// that was switched off so far (bDataMax/Min/Avg, K:471-476) is still None in the reference and is seeded by copy
+// the first time its flag is on (data_cumu(None) -> np.copy, K:133-134) -- per curve, not per engine.
+__global__ void commit_kernel(const float* partial, float* state, int n, int has_max, int has_min, int has_avg,
                               long long total_frames, int b_max, int b_min, int b_avg) {
   const int bin = blockIdx.x * blockDim.x + threadIdx.x;
   if (bin >= n) return;
   const float mx = partial[bin], cur = partial[n + bin], mn = -partial[2 * n + bin], sum = partial[3 * n + bin];
   state[bin] = cur;
-  if (b_max) state[n + bin] = has_prev ? nan_max(state[n + bin], mx) : mx;
-  if (b_min) state[2 * n + bin] = has_prev ? nan_min(state[2 * n + bin], mn) : mn;
+  if (b_max) state[n + bin] = has_max ? nan_max(state[n + bin], mx) : mx;
+  if (b_min) state[2 * n + bin] = has_min ? nan_min(state[2 * n + bin], mn) : mn;
   if (b_avg) {
     float a = sum;
-    if (has_prev) {
+    if (has_avg) {
       const float prev = state[3 * n + bin];
       const float w = total_frames > 160 ? 0.f : ldexpf(1.0f, -(int)total_frames);
       a += (fabsf(prev) < __builtin_inff()) ? prev * w : prev;
@@ -670,14 +672,19 @@ __global__ void commit_kernel(const float* partial, float* state, int n, int has
 // The reference copies the first covering step (RAW, K:644) and halves-in every later one (AVG,
 // K:649); after the last covering step the value is final and is what Max/Min/Avg see (K:657-668).
 struct StitchParams {
-  const float* step_db;  // [nsteps][N]
+  const float* step_db;  // [npasses][nsteps][N]
   int n, nsteps, hop, total;
   float* state;          // [4][total] : cur, max, min, avg
-  int first_pass;        // pass 0 seeds Avg by copy (K:615-618)
+  int first_pass;        // the first pass of this call is pass 0 of the run: it seeds Avg by copy (K:615-618)
   int b_max, b_min;
   int base_is_raw;       // bScanRangeBaseDataIsRaw (K:651-656): Max/Min/Avg see every covering step's own spectrum
+  int npasses;           // passes folded by this call, in order (a batch of captured passes resident in HBM)
+  float* avg_rows;       // [npasses - avg_row0][total] Fft.Avg after each of the last passes (waterfall source), or null
+  int avg_row0;
 };
 
+// One thread = one element of the stitched range, walking the passes of the batch in order: exactly the
+// sequence of updates the reference applies pass after pass, with the state in registers in between.
 __global__ void scan_stitch_kernel(const StitchParams p) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= p.total) return;
@@ -685,26 +692,35 @@ __global__ void scan_stitch_kernel(const StitchParams p) {
   if (e - p.n + 1 <= 0) i0 = 0;
   int i1 = e / p.hop;
   if (i1 > p.nsteps - 1) i1 = p.nsteps - 1;
-  if (i0 > i1) return;                 // not covered this pass: state keeps its value
-  float cur = p.step_db[(long long)i0 * p.n + (e - i0 * p.hop)];
-  for (int i = i0 + 1; i <= i1; ++i) cur = (cur + p.step_db[(long long)i * p.n + (e - i * p.hop)]) * 0.5f;
+  const bool covered = i0 <= i1;       // not covered: the state keeps its value
   const int tot = p.total;
-  p.state[e] = cur;
-  if (!p.base_is_raw) {
-    if (p.b_max) p.state[tot + e] = nan_max(p.state[tot + e], cur);
-    if (p.b_min) p.state[2 * tot + e] = nan_min(p.state[2 * tot + e], cur);
-    p.state[3 * tot + e] = p.first_pass ? cur : (p.state[3 * tot + e] + cur) * 0.5f;
-  } else {
-    // every covering step, in order, folds its own spectrum in (pass 0: Avg is overwritten by each step)
-    float mx = p.state[tot + e], mn = p.state[2 * tot + e], av = p.state[3 * tot + e];
-    for (int i = i0; i <= i1; ++i) {
-      const float x = p.step_db[(long long)i * p.n + (e - i * p.hop)];
-      mx = nan_max(mx, x);
-      mn = nan_min(mn, x);
-      av = p.first_pass ? x : (av + x) * 0.5f;
+  float cur = p.state[e], mx = p.state[tot + e], mn = p.state[2 * tot + e], av = p.state[3 * tot + e];
+  for (int ps = 0; ps < p.npasses; ++ps) {
+    if (covered) {
+      const float* db = p.step_db + (long long)ps * p.nsteps * p.n;
+      const bool first = p.first_pass && ps == 0;
+      cur = db[(long long)i0 * p.n + (e - i0 * p.hop)];
+      for (int i = i0 + 1; i <= i1; ++i) cur = (cur + db[(long long)i * p.n + (e - i * p.hop)]) * 0.5f;
+      if (!p.base_is_raw) {
+        if (p.b_max) mx = nan_max(mx, cur);
+        if (p.b_min) mn = nan_min(mn, cur);
+        av = first ? cur : (av + cur) * 0.5f;
+      } else {
+        // every covering step, in order, folds its own spectrum in (pass 0: Avg is overwritten by each step)
+        for (int i = i0; i <= i1; ++i) {
+          const float x = db[(long long)i * p.n + (e - i * p.hop)];
+          if (p.b_max) mx = nan_max(mx, x);
+          if (p.b_min) mn = nan_min(mn, x);
+          av = first ? x : (av + x) * 0.5f;
+        }
+      }
     }
-    if (p.b_max) p.state[tot + e] = mx;
-    if (p.b_min) p.state[2 * tot + e] = mn;
+    if (p.avg_rows && ps >= p.avg_row0) p.avg_rows[(long long)(ps - p.avg_row0) * tot + e] = av;
+  }
+  if (covered) {
+    p.state[e] = cur;
+    p.state[tot + e] = mx;
+    p.state[2 * tot + e] = mn;
     p.state[3 * tot + e] = av;
   }
 }
@@ -734,8 +750,96 @@ __global__ void levels_kernel(const float* src, const float* adj, int n, int cel
   out[(long long)blockIdx.y * cells + c] = nan ? __builtin_nanf("") : acc;
 }
 
+// Peak markers of plot_highs (K:243-272) on the device.  The reference walks the points of the plotted curve from
+// the highest level down (ascending argsort read backwards, K:253-258) and marks a point unless an already marked
+// one lies closer than delta4Marking along the frequency axis (K:261-262), until numMarkers are marked (K:268).
+// That greedy walk is "count" rounds of: arg-max over the points not excluded by the marks so far.  The axis of the
+// plotted curve is uniform, so the spacing rule is |c - m| < min_sep in cells (min_sep = delta / cell width, host
+// computed).  Two details of the reference are kept: NaN sorts above +inf (numpy's argsort puts NaN last, so the
+// walk meets it first), and the walk stops one short of the lowest point (K:258: i = -1 .. -(len-1)), which is
+// therefore never marked.  Equal levels: the higher index first.  One workgroup; lv = [cells] decimated curve.
+struct HighsParams {
+  const float* lv;
+  int cells;
+  double min_sep;
+  int count;        // <= HIGHS_MAX
+  int* idx;         // [count] marked cell, in marking order
+  float* lvl;       // [count]
+  int* found;       // number marked (< count when the curve runs out of eligible points)
+};
+constexpr int HIGHS_MAX = 64;
+
+__device__ __forceinline__ unsigned order_bits(float v) {
+  if (v != v) return 0xffffffffu;                       // NaN above everything
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);    // monotone map of the float order onto unsigned
+}
+
+__device__ __forceinline__ unsigned long long wg_reduce_max(unsigned long long k, unsigned long long* sh, bool want_min) {
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned hi = __shfl_xor((unsigned)(k >> 32), m), lo = __shfl_xor((unsigned)k, m);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    k = want_min ? (o < k ? o : k) : (o > k ? o : k);
+  }
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[wave] = k;
+  __syncthreads();
+  unsigned long long r = sh[0];
+  for (int w = 1; w < nw; ++w) r = want_min ? (sh[w] < r ? sh[w] : r) : (sh[w] > r ? sh[w] : r);
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void highs_kernel(const HighsParams p) {
+  __shared__ unsigned long long sh[16];
+  __shared__ int marks[HIGHS_MAX];
+  const int tid = threadIdx.x;
+  // the lowest point (lowest index among equals; NaN never counts as low): not part of the walk
+  unsigned long long kmin = ~0ull;
+  for (int c = tid; c < p.cells; c += blockDim.x) {
+    const unsigned long long k = ((unsigned long long)order_bits(p.lv[c]) << 32) | (unsigned)c;
+    kmin = k < kmin ? k : kmin;
+  }
+  const int lowest = (int)(unsigned)wg_reduce_max(kmin, sh, true);
+  int nm = 0;
+  for (; nm < p.count; ++nm) {
+    unsigned long long best = 0;   // 0 = nothing eligible (real keys are stored +1)
+    for (int c = tid; c < p.cells; c += blockDim.x) {
+      if (c == lowest) continue;
+      bool free_ = true;
+      for (int j = 0; j < nm; ++j) free_ &= c != marks[j] && fabs((double)(c - marks[j])) >= p.min_sep;   // (each point is visited once)
+      if (!free_) continue;
+      const unsigned long long k = (((unsigned long long)order_bits(p.lv[c]) << 32) | (unsigned)c) + 1ull;
+      best = k > best ? k : best;
+    }
+    best = wg_reduce_max(best, sh, false);
+    if (best == 0) break;
+    const int c = (int)(unsigned)(best - 1ull);
+    if (tid == 0) { marks[nm] = c; p.idx[nm] = c; p.lvl[nm] = p.lv[c]; }
+    __syncthreads();
+  }
+  if (tid == 0) *p.found = nm;
+}
+
 __global__ void fill_kernel(float* dst, long long n, float v) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+// Scan waterfall rows of a batch of passes (K:696-697): row r of `src` ([rows][cells*g], Fft.Avg after a pass)
+// -> ring row (row0 + r) % 128.  blockIdx.y = r.
+__global__ void rowmax_rows_kernel(const float* src, const float* adj, int cells, int g, float* ring, int row0) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cells) return;
+  const float* row = src + (long long)blockIdx.y * cells * g;
+  float hv = -__builtin_inff();
+  bool nan = false;
+  for (int i = 0; i < g; ++i) {
+    float v = row[(long long)c * g + i];
+    if (adj) v -= adj[(long long)c * g + i];
+    nan |= v != v;
+    hv = fmaxf(hv, v);
+  }
+  ring[(long long)((row0 + blockIdx.y) % HM_ROWS) * cells + c] = nan ? __builtin_nanf("") : hv;
 }
 
 // out[c] = max_{i<g} (src[c*g+i] - adj[c*g+i])

@@ -90,7 +90,8 @@ def merge_gathered_reference(gathered, n, hm_w, idx0, frames_per_rank):
 
 
 class ShardedZeroSpan:
-    """Drives one engine per rank; with world == 1 it is a plain frames_dev call."""
+    """Drives one engine per rank; with world == 1 it is a plain frames_dev call.  Stream contract: every step
+    re-points the engine at torch's current stream (_follow_current_stream), the stream RCCL orders against."""
 
     def __init__(self, engine, rank=0, world=1, group=None, always_collective=False):
         self.eng, self.rank, self.world, self.group = engine, rank, world, group
@@ -103,6 +104,7 @@ class ShardedZeroSpan:
     def step(self, iq, fmt, frames, cur_db=None, hm_rows=None):
         """Every rank passes its own `frames` capture blocks (its time chunk of a world*frames run)."""
         eng = self.eng
+        _follow_current_stream(eng)
         if not self.collective:
             eng.frames_dev(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
             self.hm_index = (self.hm_index + frames) % HM_ROWS
@@ -130,40 +132,58 @@ def step_range(nsteps, rank, world):
 
 
 def gather_steps(local, nsteps, rank, world, group=None):
-    """local: float32[hi-lo, N] per-step spectra of this rank's bands -> float32[nsteps, N] on every rank.
-    Shares differ by at most one step, so every rank pads to the largest share for one all_gather."""
+    """local: float32[hi-lo, N] per-step spectra of this rank's bands (or [P, hi-lo, N] for a batch of P passes)
+    -> float32[nsteps, N] ([P, nsteps, N]) on every rank.  Shares differ by at most one step, so every rank pads
+    to the largest share and ONE all-gather moves the whole batch."""
     if world == 1:
         return local
-    n = local.shape[1]
+    squeeze = local.dim() == 2
+    if squeeze:
+        local = local.unsqueeze(0)
+    npasses, mine, n = local.shape
     most = max(step_range(nsteps, r, world)[1] - step_range(nsteps, r, world)[0] for r in range(world))
-    pad = torch.zeros((most, n), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    out = torch.empty((nsteps, n), dtype=local.dtype, device=local.device)
+    pad = torch.zeros((npasses, most, n), dtype=local.dtype, device=local.device)
+    pad[:, :mine] = local
+    recv = torch.empty((world,) + tuple(pad.shape), dtype=local.dtype, device=local.device)
+    all_gather_flat(recv.view(world, -1), pad.view(-1), group)
+    out = torch.empty((npasses, nsteps, n), dtype=local.dtype, device=local.device)
     for r in range(world):
         lo, hi = step_range(nsteps, r, world)
-        out[lo:hi] = parts[r][:hi - lo]
-    return out
+        out[:, lo:hi] = recv[r, :, :hi - lo]
+    return out[0] if squeeze else out
+
+
+def _follow_current_stream(eng):
+    """torch.distributed collectives are ordered against torch's CURRENT stream; libksa launches on the engine's
+    stream.  Both must be the same stream, or the all-gather could read the exchange block before the kernels that
+    fill it have run (and the merge could read the receive buffer before the gather lands).  The sharded drivers
+    therefore re-point the engine at torch's current stream at every call -- callers may switch streams freely."""
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
 
 
 class ShardedScan:
-    """One scan pass over G GPUs: the steps (tuned bands, each with its own IQ capture) are independent up to
-    their dB spectrum (K:636-641), so rank r transforms steps [lo, hi); one all-gather of float32[steps][N]
-    (153 KiB at quickFullScan, 1.1 MiB at fmScan) hands every rank the whole pass and each rank runs the
-    stitch + Max/Min/Avg + waterfall-row kernels on it (K:643-668, K:696-697) -- identical state everywhere,
-    no second collective."""
+    """Scan passes over G GPUs: the steps (tuned bands, each with its own IQ capture) are independent up to
+    their dB spectrum (K:636-641), so rank r transforms steps [lo, hi) of every pass; one all-gather of
+    float32[passes][steps][N] per batch (153 KiB per pass at quickFullScan, 1.1 MiB at fmScan) hands every rank the
+    whole batch and each rank runs the stitch + Max/Min/Avg + waterfall-row kernels on it (K:643-668, K:696-697)
+    -- identical state everywhere, no second collective.  Stream contract: see _follow_current_stream."""
 
     def __init__(self, engine, rank=0, world=1, group=None):
         self.eng, self.rank, self.world, self.group = engine, rank, world, group
 
     def run_pass(self, iq_local, fmt, nsteps):
         """iq_local: this rank's capture blocks, [hi-lo] frames of fullSize samples, on its GPU."""
+        self.run_passes(iq_local, fmt, nsteps, 1)
+
+    def run_passes(self, iq_local, fmt, nsteps, npasses):
+        """iq_local: [npasses][hi-lo] capture blocks of this rank (pass-major), on its GPU."""
         from ._lib import OUT_DB_CLIP
         eng = self.eng
+        _follow_current_stream(eng)
         lo, hi = step_range(nsteps, self.rank, self.world)
-        local = torch.empty((max(hi - lo, 1), eng.fft_size), dtype=torch.float32, device="cuda")
-        if hi > lo:
-            eng.curscan_dev(iq_local, fmt, hi - lo, local, out_mode=OUT_DB_CLIP)
-        full = gather_steps(local[:hi - lo], nsteps, self.rank, self.world, self.group)
-        eng.scan_stitch_dev(full.contiguous(), nsteps)
+        mine = hi - lo
+        local = torch.empty((npasses, max(mine, 1), eng.fft_size), dtype=torch.float32, device="cuda")
+        if mine > 0:
+            eng.curscan_dev(iq_local, fmt, npasses * mine, local, out_mode=OUT_DB_CLIP)
+        full = gather_steps(local[:, :mine], nsteps, self.rank, self.world, self.group)
+        eng.scan_stitch_dev(full.contiguous(), nsteps, npasses)

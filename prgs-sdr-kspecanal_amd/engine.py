@@ -260,8 +260,14 @@ class SpectrumEngine:
             ok = np.ascontiguousarray(step_ok, dtype=np.uint8)
         check(lib.ksa_scan_pass_dev(self._h, _ptr(iq), fmt, stride, int(nsteps), _ptr(ok)))
 
-    def scan_stitch_dev(self, step_db, nsteps):
-        check(lib.ksa_scan_stitch_dev(self._h, _ptr(step_db), int(nsteps)))
+    def scan_stitch_dev(self, step_db, nsteps, npasses=1):
+        check(lib.ksa_scan_stitch_passes_dev(self._h, _ptr(step_db), int(nsteps), int(npasses)))
+
+    def scan_passes_dev(self, iq, fmt, nsteps, npasses, step_ok=None, frame_stride=None):
+        """A batch of captured passes ([npasses][nsteps] blocks) in one call: same state as pass-by-pass calls."""
+        stride = self.full_size if frame_stride is None else int(frame_stride)
+        ok = None if step_ok is None else np.ascontiguousarray(step_ok, dtype=np.uint8)
+        check(lib.ksa_scan_passes_dev(self._h, _ptr(iq), fmt, stride, int(nsteps), int(npasses), _ptr(ok)))
 
     def scan_state(self):
         t = self.scan_total
@@ -287,6 +293,18 @@ class SpectrumEngine:
         out = np.empty((4, int(cells)), dtype=np.float32)
         check(lib.ksa_read_levels(self._h, int(bool(scan)), code, int(cells), _ptr(out)))
         return out.astype(np.float64)
+
+    def highs(self, cells, mode="AVG", curve="cur", min_sep=0.0, count=5, scan=False):
+        """plot_highs (K:243-272) on the device: the cells of the decimated curve that the reference would mark,
+        in marking order.  min_sep = delta4Marking in units of cells.  Returns (idx int32[found], levels float64[found])."""
+        code = {"AVG": 0, "MAX": 1, "MIN": 2}[mode.upper()]
+        cv = {"cur": 0, "max": 1, "min": 2, "avg": 3}[curve.lower()]
+        idx = np.empty(int(count), dtype=np.int32)
+        lvl = np.empty(int(count), dtype=np.float32)
+        found = C.c_int32()
+        check(lib.ksa_read_highs(self._h, int(bool(scan)), code, int(cells), cv, float(min_sep), int(count),
+                                 _ptr(idx), _ptr(lvl), C.byref(found)))
+        return idx[:found.value].copy(), lvl[:found.value].astype(np.float64)
 
     # -- measurement ------------------------------------------------------------------------------------
     def prof_enable(self, on=True):

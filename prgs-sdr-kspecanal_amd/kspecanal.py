@@ -226,11 +226,35 @@ def get_engine(d, scan_total=0, max_frames=1):
     return d["ksa.engine"]
 
 
+def psd_crosscheck(d, samples, mag):
+    """bUsePSD (K:350, K:374-384, README.rst:523-529) as a CPU-only DIAGNOSTIC next to the GPU result, never in
+    place of it: matplotlib's Welch PSD of the same block (mlab.psd, the routine behind plt.psd at K:382: Fs = 2,
+    two-sided, scale_by_freq, mean over segments) is converted back to this program's amplitude convention
+    (|X| = sqrt(P * Fs * sum(w^2)), then 2*winAdj/N as K:391) and compared at the strongest bin.  The reference's own
+    branch passes a float `noverlap` and raises TypeError under matplotlib >= 3.8 (observed with 3.10 in the build
+    container), so there is no reference-run vector for it: parity unpinned, diagnostic only.  Stores d['psd.cur']
+    (the PSD, fftshifted) and d['psd.check'] = (bin_gpu, bin_psd, level_gpu_dB, level_psd_dB)."""
+    from matplotlib import mlab
+    n, win = d["fftSize"], np.asarray(d["theWin"], dtype=np.float64)
+    x = np.asarray(samples)
+    if x.dtype == np.uint8:
+        x = (x[0::2].astype(np.float64) - 127.5) / 127.5 + 1j * ((x[1::2].astype(np.float64) - 127.5) / 127.5)
+    pxx, _ = mlab.psd(x.astype(np.complex128), NFFT=n, window=win, noverlap=int(n * (1 - d["curScanNonOverlap"])))
+    amp = np.sqrt(pxx * 2.0 * np.sum(win ** 2)) * 2.0 * (n / np.sum(win)) / n
+    kg, kp = int(np.argmax(mag)), int(np.argmax(amp))
+    with np.errstate(divide="ignore"):
+        lg, lp = 10 * np.log10(mag[kg]) - d["gain"], 10 * np.log10(amp[kp]) - d["gain"]
+    d["psd.cur"], d["psd.check"] = pxx, (kg, kp, float(lg), float(lp))
+    print("DBUG:bUsePSD: peak bin gpu[{}] psd[{}] level gpu[{:.3f}] psd[{:.3f}] dB".format(kg, kp, lg, lp))
+
+
 def sdr_curscan(d):
     """Drop-in for K:351-397: float64[fftSize] linear magnitudes, fftshifted."""
+    samples = sdr_read(d, d["fullSize"])
+    mag = get_engine(d).curscan(samples)
     if d["bUsePSD"]:
-        prg_quit(d, "ERROR: bUsePSD is a matplotlib cross-check of the reference's CPU path; not available here")
-    return get_engine(d).curscan(sdr_read(d, d["fullSize"]))
+        psd_crosscheck(d, samples, mag)
+    return mag
 
 
 _gpu_curscan = sdr_curscan   # zero_span fuses curscan + accumulate on the device while this is still bound
@@ -345,15 +369,26 @@ def data_plotcompress(d, x, y, mode=None):
     return _plotcompress(d, x, "AVG"), _plotcompress(d, y, mode)
 
 
-def plot_highs(d, freqs, levels):
-    """K:243-272: the strongest bins, at least pltHighsDelta4Marking of the span apart.  Returns the list."""
+def plot_highs(d, freqs, levels, eng=None, curve=None, scan=False):
+    """K:243-272: the strongest points of the last plotted curve, at least pltHighsDelta4Marking of the span apart.
+    With an engine the selection runs on the device over the same decimated curve (ksa_read_highs) and only the
+    marked cells come back; otherwise (RAW / CONV curves that are on the host anyway) the same walk runs here:
+    descending argsort, the lowest point never visited (K:258).  Returns the list of (freq, level)."""
     delta = d["pltHighsDelta4Marking"] * (freqs[-1] - freqs[0])
+    count = d["pltHighsNumMarkers"]
     marked = []
-    for i in np.argsort(levels)[::-1]:
-        if all(abs(freqs[i] - f) >= delta for f, _ in marked):
-            marked.append((float(freqs[i]), float(levels[i])))
-            if len(marked) >= d["pltHighsNumMarkers"]:
-                break
+    if eng is not None and curve is not None and 1 <= count <= 64 and len(freqs) > 1:
+        cell = (freqs[-1] - freqs[0]) / (len(freqs) - 1)
+        idx, lvl = eng.highs(len(freqs), d["pltCompress"], curve, min_sep=delta / cell, count=count, scan=scan)
+        marked = [(float(freqs[i]), float(v)) for i, v in zip(idx, lvl)]
+    else:
+        order = np.argsort(levels)
+        for j in range(1, len(freqs)):
+            i = order[-j]
+            if all(abs(freqs[i] - f) >= delta for f, _ in marked):
+                marked.append((float(freqs[i]), float(levels[i])))
+                if len(marked) >= count:
+                    break
     d["Highs"] = marked
     if d.get("plt") is not None and d["bPltLevels"]:
         d["AxFreqs"].clear()
@@ -379,13 +414,15 @@ def _plot_levels(d, freqs, cur, eng=None, scan=False):
             d["AxLevels"].cla()
             if d["bGrid"]:
                 d["AxLevels"].grid(True)
+        last = None
         for flag, data, colour in curves:
             if d[flag]:
-                x, y = xs, data
+                x, y, last = xs, data, flag[5:].lower()                     # bDataMax -> "max"
                 if d.get("plt") is not None and d["bPltLevels"]:
                     d["AxLevels"].plot(x, y, colour)
+        d["Levels"] = {"x": xs, "max": lv[1], "min": lv[2], "avg": lv[3], "cur": lv[0]}
         if x is not None:
-            plot_highs(d, x, y)
+            plot_highs(d, x, y, eng, last, scan)                          # markers of the last plotted curve (K:504)
         return
     x = y = None
     curves = (("bDataMax", fmax, "r"), ("bDataMin", fmin, "y"), ("bDataAvg", favg, "g"), ("bDataCur", fcur, "b"))
@@ -435,13 +472,17 @@ def zero_span(d):
         print("ZeroSpan:{}:{}".format(i, now - prev))
         prev = now
         eng.set_flags(d["bDataMax"], d["bDataMin"], d["bDataAvg"])          # GUI toggles K:471-476
-        if sdr_curscan is _gpu_curscan:
+        if sdr_curscan is _gpu_curscan and not d["bUsePSD"]:
             try:
                 eng.frame(sdr_read(d, d["fullSize"]))                       # fused K:464-484
             except EOFError:
                 prg_quit(d, "WARN:zero_span: source exhausted, stoping...", False)
         else:
-            cur = sdr_curscan(d)                                            # rebound seam (playback, K:543)
+            try:
+                cur = sdr_curscan(d)                                        # rebound seam (playback, K:543) / bUsePSD
+            except EOFError:
+                cur = None
+                prg_quit(d, "WARN:zero_span: source exhausted, stoping...", False)
             if cur is not None:
                 eng.frame_spectrum(cur)
         if d["cmd.stop"]:
@@ -530,6 +571,8 @@ def scan_range(d):
     print("_scanRange: start:{} end:{} samplingRate:{}".format(d["startFreq"], d["endFreq"], d["samplingRate"]))
     print("_scanRange: totalFreqs:{} numGroups:{} totalEntries:{}".format(d["endFreq"] - d["startFreq"], groups, total))
     steps = len(centers)
+    if d["bUsePSD"]:
+        print("WARN:_scanRange: bUsePSD is a zeroSpan diagnostic here (the whole pass is one device call); ignored")
     eng = get_engine(d, scan_total=total, max_frames=steps)
     eng.scan_reset()
     eng.scan_set_base_is_raw(d["bScanRangeBaseDataIsRaw"])

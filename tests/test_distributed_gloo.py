@@ -147,3 +147,27 @@ def test_scan_band_shard_gather(tmp_path):
     x = orc.synth_iq(full * steps, 77).astype(np.complex64).reshape(steps, full)
     want = np.array([orc.curscan(x[s], n, 0.1, orc.window_table("ones", n), "AVG") for s in range(steps)], dtype=np.float32)
     assert np.array_equal(np.load(out), want)
+
+
+def _scan_batch_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ksa_dist = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
+    passes, steps, n = 3, 7, 16
+    full = torch.arange(passes * steps * n, dtype=torch.float32).reshape(passes, steps, n)
+    lo, hi = ksa_dist.step_range(steps, rank, world)
+    got = ksa_dist.gather_steps(full[:, lo:hi].contiguous(), steps, rank, world)
+    if rank == 0:
+        np.save(out_path, got.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scan_band_shard_gather_batch_of_passes(tmp_path):
+    """The multi-pass form: every rank holds [passes][its bands][N]; one all-gather rebuilds [passes][steps][N]."""
+    load_pkg()
+    out = str(tmp_path / "batch.npy")
+    mp.spawn(_scan_batch_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    want = np.arange(3 * 7 * 16, dtype=np.float32).reshape(3, 7, 16)
+    assert np.array_equal(np.load(out), want)

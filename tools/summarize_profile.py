@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the tracked summaries under profiles/:
-   <tag>_kernel_stats.csv  rocprofv3 --kernel-trace --stats table
-   <tag>_pmc.json          per-kernel mean counters + derived HBM traffic
-   pmc_traffic.json        what bench.py reports as roofline.traffic for the same workload
-HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB;
-on gfx950 FETCH_SIZE counts half the bytes of a coalesced stream -- verified for this kernel's own access
-shape with tools/fetch_calib.hip (ratio 0.5000 for 8 B/lane windowed buffer loads and for 16 B/lane streams),
-so bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
+"""Condense gpurun_out/prof_<tag> (written by tools/profile_bench.sh on the GPU box) into profiles/<tag>_*:
+  <tag>_kernel_stats.csv  the rocprofv3 --kernel-trace --stats table
+  <tag>_pmc.json          per-kernel mean counters + the bench line of the same run
+and record the dominant kernels' HBM traffic per bench step in profiles/pmc_traffic.json under the key
+"<config>:<fmt>:<units per step>", stamped with the hash of the kernel sources (bench.py reports it as
+roofline.traffic only while that hash still matches).  HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3):
+FETCH_SIZE counts 64 B per 128-B request on gfx950 -> doubled; WRITE_SIZE is exact for 16 B/lane streams; both in KiB.
+The x2 was re-checked for this code's own access shapes with tools/fetch_calib.hip (ratio 0.5000 for 8 B/lane
+windowed buffer loads and for 16 B/lane streams), so bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
 import collections, csv, glob, json, os, shutil, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
 tag = sys.argv[1]
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
@@ -33,14 +35,31 @@ if os.path.exists(bl) and os.path.getsize(bl):
 for k, c in out.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         c["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
-json.dump({"bench_line": bench, "kernels": out}, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
-spec = [c for k, c in out.items() if "spectrum_kernel" in k]
-if spec and bench:
+json.dump({"bench_line": bench, "bench_args": open(os.path.join(src, "bench_args.txt")).read().strip() if os.path.exists(os.path.join(src, "bench_args.txt")) else "",
+           "kernels": out}, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+# dominant kernels = the spectrum stage: spectrum_kernel (+ combine_parts) or the four-step kernels
+dom = {k: c for k, c in out.items() if any(s in k for s in ("spectrum_kernel", "fourstep_", "combine_parts")) and "hbm_bytes_per_launch" in c}
+if dom and bench:
+    import bench as B
     cfg = bench["config"]
-    rec = {"frames": cfg["frames_per_gpu_per_step"], "fmt": "c64" if cfg["input"] == "complex64" else "u8",
-           "hbm_bytes_per_launch": spec[0]["hbm_bytes_per_launch"], "source": "profiles/%s_pmc.json" % tag,
-           "fetch_size_kib": spec[0]["FETCH_SIZE"], "write_size_kib": spec[0]["WRITE_SIZE"]}
-    json.dump(rec, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    units = cfg.get("frames_per_gpu_per_step") or cfg["passes_per_step"] * cfg["bands_on_rank0"]
+    fmt = "c64" if cfg["input"] == "complex64" else "u8"
+    steps_in_pmc_run = 4        # profile_bench.sh: --steps 3 --warmup 1
+    total = sum(c["hbm_bytes_per_launch"] * c["launches_pmc_fetch"] for c in dom.values())
+    per_step = total / steps_in_pmc_run
+    path = os.path.join(dst, "pmc_traffic.json")
+    rec = {"entries": {}}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+            if "entries" in old:
+                rec = old
+        except Exception:
+            pass
+    key = "%d:%s:%d" % (cfg["baseline_config"], fmt, units)
+    rec["entries"][key] = {"hbm_bytes_per_launch": per_step, "csrc_sha256": B.csrc_sha256(), "source": "profiles/%s_pmc.json" % tag,
+                           "kernels": sorted(dom)}
+    json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
     alg = bench["roofline"]["algorithmic_bytes_per_launch"]
-    print("traffic %.3f GB per launch vs algorithmic %.3f GB (x%.2f)" % (rec["hbm_bytes_per_launch"] / 1e9, alg / 1e9, rec["hbm_bytes_per_launch"] / alg))
-print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read()[:900])
+    print("%s: traffic %.3f GB per step vs algorithmic %.3f GB (x%.2f)" % (key, per_step / 1e9, alg / 1e9, per_step / alg))
+print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read()[:1200])
