@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/ksa.h"
+#include "ksa_dif16.hpp"
 #include "ksa_fourstep.hpp"
 #include "ksa_kernels.hpp"
 
@@ -36,6 +37,11 @@ int fail(const char* fmt, ...) {
   } while (0)
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// default first-stage scratch per chunk of frames (ksa_dif16.hpp); tuned on MI355X, see DESIGN.md 4.2
+#ifndef KSA_DIF_SCRATCH_MB_DEFAULT
+#define KSA_DIF_SCRATCH_MB_DEFAULT 4096
+#endif
 
 // host mirrors of ksa::Tune<N>::FUSED / FUSED_LAST (the twiddle table layouts depend on them)
 bool tune_fused(int n) {
@@ -84,7 +90,15 @@ struct ksa_engine {
   int* d_highs = nullptr;         // peak markers: [HIGHS_MAX] cell | [HIGHS_MAX] level (float bits) | found
   float* d_parts = nullptr;       // [capacity][N] partial folds of the window-split (latency) mode
   int levels_cap = 0;
-  ksa::FourStep four;           // N > 16384
+  ksa::FourStep four;           // N > 262144: four-step path (column / row kernels)
+  // 16384 < N <= 262144: radix-16 decimation in frequency in front of the single-workgroup kernel (ksa_dif16.hpp)
+  int sub_n = 0;                // size of the single-workgroup transform: fft_size (path 0) or fft_size/16 (path 2)
+  float2* d_dif_tw = nullptr;   // [6][N1]
+  float2* d_dif_z = nullptr;    // [chunk][16][nwin][N1]
+  float* d_dif_y = nullptr;     // [chunk][16][N1]
+  float* d_ones = nullptr;      // [N1] taps of the second stage (the window was applied in the first)
+  int* d_starts_b = nullptr;    // [nwin] w*N1
+  int dif_chunk = 1;
   // bookkeeping
   long long frames_seen = 0;
   int hm_index = 0;
@@ -184,7 +198,7 @@ int launch_spec_rm(ksa_engine* e, const SpecParams& p, bool cfg_only, int rm) {
 template <int FMT>
 int launch_spec_n(ksa_engine* e, const SpecParams& p, bool cfg_only) {
   const int rm = p.nwin > 1 ? e->reuse_m : 0;   // RAW mode transforms a single window: nothing to reuse
-  switch (e->cfg.fft_size) {
+  switch (e->sub_n) {
     case 16: return launch_spec_rm<16, FMT>(e, p, cfg_only, rm);
     case 32: return launch_spec_rm<32, FMT>(e, p, cfg_only, rm);
     case 64: return launch_spec_rm<64, FMT>(e, p, cfg_only, rm);
@@ -196,7 +210,7 @@ int launch_spec_n(ksa_engine* e, const SpecParams& p, bool cfg_only) {
     case 4096: return launch_spec_rm<4096, FMT>(e, p, cfg_only, rm);
     case 8192: return launch_spec_rm<8192, FMT>(e, p, cfg_only, rm);
     case 16384: return launch_spec_rm<16384, FMT>(e, p, cfg_only, rm);
-    default: return fail("fft_size %d has no single-workgroup plan", e->cfg.fft_size);
+    default: return fail("fft_size %d has no single-workgroup plan", e->sub_n);
   }
 }
 
@@ -212,6 +226,65 @@ int prof_end(ksa_engine* e, hipEvent_t a, hipEvent_t b) {
   if (!a) return 0;
   HIP_OK(hipEventRecord(b, e->stream));
   e->prof_events.emplace_back(a, b);
+  return 0;
+}
+
+// N = 16 * N1 (32768 .. 262144): first stage in registers, N1-point stage by the single-workgroup kernel on the
+// 16 pseudo frames of every frame, interleave + dB + waterfall by dif16_finish_kernel (ksa_dif16.hpp).
+int run_dif16(ksa_engine* e, const SpecParams& p, int fmt) {
+  const int n = e->cfg.fft_size, n1 = e->sub_n, nwin = p.nwin;
+  for (int f0 = 0; f0 < p.nframes; f0 += e->dif_chunk) {
+    const int cf = std::min(e->dif_chunk, p.nframes - f0);
+    ksa::DifParams a{};
+    a.iq = p.iq;
+    a.frame_stride = p.frame_stride;
+    a.frame0 = f0;
+    a.nwin = nwin;
+    a.starts = p.starts;
+    a.window = p.window;
+    a.tw = e->d_dif_tw;
+    a.n1 = n1;
+    a.u8_offset = p.u8_offset;
+    a.u8_inv_scale = p.u8_inv_scale;
+    a.z = e->d_dif_z;
+    const dim3 ga(n1 / 512, nwin, cf);     // two adjacent n1 per thread
+    if (fmt == KSA_FMT_C64) hipLaunchKernelGGL(ksa::dif16_kernel<ksa::FMT_C64>, ga, dim3(256), 0, e->stream, a);
+    else hipLaunchKernelGGL(ksa::dif16_kernel<ksa::FMT_U8>, ga, dim3(256), 0, e->stream, a);
+    SpecParams b{};
+    b.iq = e->d_dif_z;
+    b.frame_stride = (long long)nwin * n1;
+    b.frame_len = nwin * n1;
+    b.nframes = cf * 16;
+    b.nwin = nwin;
+    b.starts = e->d_starts_b;      // w * N1 (a single window, RAW mode, starts at 0 too)
+    b.window = e->d_ones;
+    b.tw_mid = p.tw_mid;
+    b.tw_last = p.tw_last;
+    b.scale = p.scale;
+    b.cumu = p.cumu;
+    b.out_mode = ksa::OUT_LINEAR;
+    b.out = e->d_dif_y;
+    if (launch_spec_n<ksa::FMT_C64>(e, b, false)) return 1;
+    ksa::DifFinishParams c{};
+    c.y = e->d_dif_y;
+    c.n = n;
+    c.n1 = n1;
+    c.frame0 = f0;
+    c.out_mode = p.out_mode;
+    c.gain = p.gain;
+    c.min_amp = p.min_amp;
+    c.out = p.out;
+    c.hm_w = p.hm_w;
+    c.adj = p.adj;
+    c.hm_rows = p.hm_rows;
+    c.hm_ring = p.hm_ring;
+    c.hm_index0 = p.hm_index0;
+    c.hm_first = p.hm_first;
+    hipLaunchKernelGGL(ksa::dif16_finish_kernel, dim3(n1 / 64, cf), dim3(256), 0, e->stream, c);
+  }
+  if (p.hm_w > 0 && n / p.hm_w > 1024)      // cells wider than the finish kernel's tile
+    hipLaunchKernelGGL(ksa::rowmax_batch, dim3((p.hm_w + 255) / 256, p.nframes), dim3(256), 0, e->stream, p, n);
+  HIP_OK(hipGetLastError());
   return 0;
 }
 
@@ -265,6 +338,8 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
   if (e->path == 1) {
     rc = ksa::fourstep_run(e->four, p, fmt, e->stream, e->num_cu);
     if (rc) return fail("four-step launch failed: %s", hipGetErrorString(hipGetLastError()));
+  } else if (e->path == 2) {
+    if ((rc = run_dif16(e, p, fmt))) return rc;
   } else {
     rc = fmt == KSA_FMT_C64 ? launch_spec_n<ksa::FMT_C64>(e, p, false) : launch_spec_n<ksa::FMT_U8>(e, p, false);
     if (rc) return rc;
@@ -412,12 +487,14 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   if ((rc = upload(&e->d_start_last, cfg->window_starts + cfg->num_windows - 1, 1))) return bail(rc);
   if ((rc = upload(&e->d_window, cfg->window, (size_t)n))) return bail(rc);
 
-  if (n <= 16384) {
-    e->path = 0;
+  if (n <= 262144) {
+    e->path = n <= 16384 ? 0 : 2;
+    const int sn = e->path == 0 ? n : n / 16;     // the single-workgroup transform
+    e->sub_n = sn;
     const int pt = 16, lpt = 4;   // 16 points per thread, radix-16 passes (an 8-point / radix-8 plan measured 20 % slower)
-    const bool fused_mid = tune_fused(n), fused_last = tune_fused_last(n);   // layouts must match ksa::Tune<N>
+    const bool fused_mid = tune_fused(sn), fused_last = tune_fused_last(sn);   // layouts must match ksa::Tune<N>
     // twiddles in double, stored as float: middle passes [pt-1][p] each, last pass [pt-1][N/pt]
-    const int log2n = ksa::ilog2(n);
+    const int log2n = ksa::ilog2(sn);
     const int m = (log2n + lpt - 1) / lpt;
     const int r0 = 1 << (log2n - lpt * (m - 1));
     std::vector<float2> mid, last;
@@ -448,7 +525,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     if ((rc = upload(&e->d_tw_mid, mid.data(), mid.size()))) return bail(rc);
     if ((rc = upload(&e->d_tw_last, last.data(), last.size()))) return bail(rc);
     // constant hop of 1/2 or 1/4 of the transform: raw samples are carried over in registers
-    if (cfg->num_windows > 1 && n >= 1024) {
+    if (e->path == 0 && cfg->num_windows > 1 && n >= 1024) {
       const int hop = cfg->window_starts[1] - cfg->window_starts[0];
       bool same = true;
       for (int i = 2; i < cfg->num_windows; ++i) same &= cfg->window_starts[i] - cfg->window_starts[i - 1] == hop;
@@ -459,6 +536,33 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     dummy.nwin = cfg->num_windows;
     if ((rc = launch_spec_n<ksa::FMT_C64>(e, dummy, true))) return bail(rc);
     if ((rc = launch_spec_n<ksa::FMT_U8>(e, dummy, true))) return bail(rc);
+    if (e->path == 2) {
+      const int n1 = sn, nw = cfg->num_windows;
+      // first-stage output twiddles W_N^(n1*e), e = 1,2,3,4,8,12 (float64-generated); w^k2 = w^(k2&3) * w^(k2&12)
+      static const int ex[6] = {1, 2, 3, 4, 8, 12};
+      std::vector<float2> tw((size_t)6 * n1);
+      for (int r = 0; r < 6; ++r)
+        for (int k = 0; k < n1; ++k) {
+          const double ang = -2.0 * M_PI * (double)ex[r] * (double)k / (double)n;
+          tw[(size_t)r * n1 + k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+      if ((rc = upload(&e->d_dif_tw, tw.data(), tw.size()))) return bail(rc);
+      std::vector<float> ones((size_t)n1, 1.0f);
+      if ((rc = upload(&e->d_ones, ones.data(), ones.size()))) return bail(rc);
+      std::vector<int> sb((size_t)nw);
+      for (int w = 0; w < nw; ++w) sb[w] = w * n1;
+      if ((rc = upload(&e->d_starts_b, sb.data(), sb.size()))) return bail(rc);
+      // scratch: Z = 8 N bytes per window.  Chunks of <= KSA_FS_SCRATCH_MB (default below) of Z
+      const size_t per_frame = (size_t)nw * n * sizeof(float2);
+      size_t budget = (size_t)KSA_DIF_SCRATCH_MB_DEFAULT << 20;
+      if (const char* mb = getenv("KSA_FS_SCRATCH_MB")) budget = (size_t)atol(mb) << 20;   // A/B switch for measurements
+      e->dif_chunk = (int)std::min<size_t>(std::max<size_t>(1, budget / per_frame), (size_t)cfg->max_frames);
+      hipError_t he2;
+      if ((he2 = hipMalloc(reinterpret_cast<void**>(&e->d_dif_z), per_frame * e->dif_chunk)) != hipSuccess)
+        return bail(fail("hipMalloc(%zu) for the first-stage scratch: %s", per_frame * e->dif_chunk, hipGetErrorString(he2)));
+      if ((he2 = hipMalloc(reinterpret_cast<void**>(&e->d_dif_y), (size_t)e->dif_chunk * n * 4)) != hipSuccess)
+        return bail(fail("hipMalloc for the second-stage output: %s", hipGetErrorString(he2)));
+    }
   } else {
     e->path = 1;
     if (ksa::fourstep_create(e->four, n, cfg->num_windows, cfg->max_frames, e->num_cu)) return bail(fail("four-step setup failed for fft_size %d: %s", n, hipGetErrorString(hipGetLastError())));
@@ -481,7 +585,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   e->d_partial = e->d_xchg;
   if (cfg->hm_width) e->d_hm = e->d_xchg + 4 * nn;
   ALLOC(e->d_state, 4 * nn * 4);
-  if (e->path == 0) ALLOC(e->d_parts, (size_t)e->num_cu * e->blocks_per_cu * nn * 4);
+  if (e->path != 1) ALLOC(e->d_parts, (size_t)e->num_cu * e->blocks_per_cu * (size_t)e->sub_n * 4);
   if (cfg->scan_total_entries) {
     ALLOC(e->d_scan_state, (size_t)4 * cfg->scan_total_entries * 4);
     ALLOC(e->d_scan_hm, (size_t)KSA_HM_ROWS * cfg->scan_hm_width * 4);
@@ -501,7 +605,7 @@ void ksa_destroy(ksa_engine* e) {
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   void* ptrs[] = {e->d_starts, e->d_start_last, e->d_window, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
                   e->d_iq_stage, e->d_frames, e->d_part, e->d_xchg, e->d_state, e->d_scan_state, e->d_scan_hm,
-                  e->d_levels, e->d_parts, e->d_highs, e->d_scan_avg_rows};
+                  e->d_levels, e->d_parts, e->d_highs, e->d_scan_avg_rows, e->d_dif_tw, e->d_dif_z, e->d_dif_y, e->d_ones, e->d_starts_b};
   for (void* p : ptrs) if (p) hipFree(p);
   ksa::fourstep_destroy(e->four);
   delete e;

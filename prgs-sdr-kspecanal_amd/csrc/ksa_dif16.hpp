@@ -1,0 +1,168 @@
+// Large transforms (N = 32768 .. 262144) as radix-16 decimation in frequency in front of the tuned
+// single-workgroup kernel (gfx950).  Replaces numpy.fft.fft at python/kspecanal.py:391 for those fftSize values;
+// same rows of SURVEY.md section 8 as ksa_kernels.hpp (A0, A4-A9, A12).
+//
+//   n = n1 + N1*q  (n1 < N1 = N/16, q < 16),   k = 16*k1 + k2
+//   X[16*k1 + k2] = sum_n1 W_N1^(n1*k1) * { W_N^(n1*k2) * sum_q x[n1 + N1*q] W_16^(q*k2) }
+//
+//   dif16_kernel        per (frame, window, n1): window multiply, one radix-16 butterfly in registers over the 16
+//                       samples N1 apart (lanes run along n1: every load and store is a coalesced 512-B run; no
+//                       LDS, no barrier), twiddle W_N^(n1*k2), store Z[frame][k2][window][n1].
+//   spectrum_kernel<N1> (ksa_kernels.hpp, unchanged) on the 16 "pseudo frames" (frame, k2): each is nwin
+//                       back-to-back blocks of N1 points, transformed and folded over the windows exactly as a
+//                       zeroSpan frame with hop N1 -> Y[frame][k2][k1] linear magnitudes.
+//   dif16_finish_kernel interleave k = 16*k1 + k2 through an LDS tile, fftshift, dB / clip (K:100-112), store,
+//                       waterfall cells (K:480).
+//
+// The intermediate Z (8 N bytes per window, written once and read once) is the price of a transform that does not
+// fit one workgroup's LDS; frames are processed in chunks so that Z stays within a fixed scratch budget.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ksa_kernels.hpp"
+
+namespace ksa {
+
+struct DifParams {
+  const void* iq;            // float2[] or uchar2[]; frame f at sample f*frame_stride
+  long long frame_stride;
+  int frame0;                // first frame of this chunk
+  int nwin;
+  const int* starts;         // [nwin]
+  const float* window;       // [N]
+  const float2* tw;          // [6][N1]: W_N^(n1*e) for e = 1, 2, 3, 4, 8, 12
+  int n1;                    // N / 16
+  float u8_offset, u8_inv_scale;
+  float2* z;                 // [chunk_frames][16][nwin][n1]
+};
+
+// Two adjacent n1 per thread: 16-byte loads / stores per lane (1 KiB per wave-instruction), half the
+// vector-memory instructions of the one-point form.
+template <int FMT>
+__global__ __launch_bounds__(256) void dif16_kernel(const DifParams p) {
+  const int n1 = (blockIdx.x * 256 + threadIdx.x) * 2;
+  const int w = blockIdx.y, fr = blockIdx.z;
+  const int N1 = p.n1;
+  const long long base = (long long)(p.frame0 + fr) * p.frame_stride + p.starts[w] + n1;
+  float2 va[16], vb[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float2 wn = *reinterpret_cast<const float2*>(p.window + n1 + N1 * q);
+    float2 xa, xb;
+    if constexpr (FMT == FMT_C64) {
+      // window starts are arbitrary sample offsets (K:386): 8-byte alignment only
+      const float2* src = reinterpret_cast<const float2*>(p.iq) + base + (long long)N1 * q;
+      if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const float4 x4 = *reinterpret_cast<const float4*>(src);
+        xa = make_float2(x4.x, x4.y); xb = make_float2(x4.z, x4.w);
+      } else {
+        xa = src[0]; xb = src[1];
+      }
+    } else {
+      const uchar2* src = reinterpret_cast<const uchar2*>(p.iq) + base + (long long)N1 * q;
+      uchar4 b;
+      if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+        b = *reinterpret_cast<const uchar4*>(src);
+      } else {
+        const uchar2 b0 = src[0], b1 = src[1];
+        b = make_uchar4(b0.x, b0.y, b1.x, b1.y);
+      }
+      xa = make_float2(((float)b.x - p.u8_offset) * p.u8_inv_scale, ((float)b.y - p.u8_offset) * p.u8_inv_scale);
+      xb = make_float2(((float)b.z - p.u8_offset) * p.u8_inv_scale, ((float)b.w - p.u8_offset) * p.u8_inv_scale);
+    }
+    va[q] = make_float2(xa.x * wn.x, xa.y * wn.x);
+    vb[q] = make_float2(xb.x * wn.y, xb.y * wn.y);
+  }
+  dft16(va);   // position P holds Y[perm16(P)]
+  dft16(vb);
+  // output twiddles w^k2, k2 = a + 4b: w^a * w^(4b) from six table rows (generated in float64)
+  float4 wa[4], wb[4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    wa[r + 1] = *reinterpret_cast<const float4*>(p.tw + r * N1 + n1);
+    wb[r + 1] = *reinterpret_cast<const float4*>(p.tw + (3 + r) * N1 + n1);
+  }
+  float2* const z = p.z + ((long long)fr * 16 * p.nwin + w) * N1 + n1;
+#pragma unroll
+  for (int P = 0; P < 16; ++P) {
+    const int k2 = perm<16>(P), a = k2 & 3, b = k2 >> 2;
+    float2 ya = va[P], yb = vb[P];
+    if (a && b) {
+      ya = cmul(ya, cmul(make_float2(wa[a].x, wa[a].y), make_float2(wb[b].x, wb[b].y)));
+      yb = cmul(yb, cmul(make_float2(wa[a].z, wa[a].w), make_float2(wb[b].z, wb[b].w)));
+    } else if (a) {
+      ya = cmul(ya, make_float2(wa[a].x, wa[a].y));
+      yb = cmul(yb, make_float2(wa[a].z, wa[a].w));
+    } else if (b) {
+      ya = cmul(ya, make_float2(wb[b].x, wb[b].y));
+      yb = cmul(yb, make_float2(wb[b].z, wb[b].w));
+    }
+    *reinterpret_cast<float4*>(z + (long long)k2 * p.nwin * N1) = make_float4(ya.x, ya.y, yb.x, yb.y);
+  }
+}
+
+struct DifFinishParams {
+  const float* y;            // [chunk_frames][16][N1] linear magnitudes, each row fftshifted by N1/2 (spectrum_kernel's output)
+  int n, n1;
+  int frame0;
+  int out_mode;
+  float gain, min_amp;
+  float* out;                // [nframes][N]
+  int hm_w;
+  const float* adj;
+  float* hm_rows;
+  float* hm_ring;
+  int hm_index0, hm_first;
+};
+
+// One workgroup = 64 consecutive k1 x 16 k2 = 1024 consecutive output bins of one frame.
+__global__ __launch_bounds__(256) void dif16_finish_kernel(const DifFinishParams p) {
+  __shared__ float tile[64][17];
+  __shared__ float cellv[1024];
+  const int tid = threadIdx.x;
+  const int fr = blockIdx.y;                 // frame inside the chunk
+  const int frame = p.frame0 + fr;
+  const int k1_0 = blockIdx.x * 64;
+  const int N = p.n, N1 = p.n1;
+  const float* yf = p.y + (long long)fr * 16 * N1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 256 * j, k2 = e >> 6, ko = e & 63;
+    tile[ko][k2] = yf[(long long)k2 * N1 + ((k1_0 + ko + N1 / 2) & (N1 - 1))];
+  }
+  __syncthreads();
+  const int g = p.hm_w > 0 ? N / p.hm_w : 0;
+  const bool hm_here = g > 0 && g <= 1024;   // larger cells: rowmax_batch afterwards
+  const int sh0 = (16 * k1_0 + N / 2) & (N - 1);
+  float* const orow = p.out + (long long)frame * N + sh0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j;             // k = 16*k1_0 + i
+    float lin = tile[i >> 4][i & 15];
+    float o = lin;
+    if (p.out_mode != OUT_LINEAR) {
+      if (p.out_mode == OUT_DB_CLIP) lin = fmaxf(lin, p.min_amp);
+      o = db_of(lin, p.gain);
+    }
+    orow[i] = o;
+    if (hm_here) cellv[i] = p.adj ? o - p.adj[sh0 + i] : o;
+  }
+  if (!hm_here) return;
+  __syncthreads();
+  const int cells = 1024 / g;
+  for (int c = tid; c < cells; c += 256) {
+    float hv = -__builtin_inff();
+    bool nan = false;
+    for (int i = 0; i < g; ++i) {
+      const float v = cellv[c * g + ((i + c) & (g - 1))];   // rotated start: spreads the LDS banks
+      nan |= v != v;
+      hv = fmaxf(hv, v);
+    }
+    if (nan) hv = __builtin_nanf("");
+    const int cell = sh0 / g + c;
+    if (p.hm_rows) p.hm_rows[(long long)frame * p.hm_w + cell] = hv;
+    if (p.hm_ring && frame >= p.hm_first) p.hm_ring[((p.hm_index0 + frame) % HM_ROWS) * p.hm_w + cell] = hv;
+  }
+}
+
+}  // namespace ksa

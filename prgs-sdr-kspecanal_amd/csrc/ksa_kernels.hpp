@@ -285,7 +285,10 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       if constexpr (FMT == FMT_C64) { raw[q].x = voff + q; raw[q].y = voff * q; }
       else raw[q] = voff + q;
 #else
-      if constexpr (FMT == FMT_C64) raw[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, L * q * SB, 0);
+#ifndef KSA_LOAD_AUX
+#define KSA_LOAD_AUX 0   // cache policy of the IQ loads (experiments: 2 = nt)
+#endif
+      if constexpr (FMT == FMT_C64) raw[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, L * q * SB, KSA_LOAD_AUX);
       else raw[q] = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, L * q * SB, 0);
 #endif
     }

@@ -110,13 +110,14 @@ def test_curscan_large_n_golden(ksa, tag):
 
 @pytest.mark.parametrize("tag", ["n32768_q05", "n65536_q025"])
 def test_curscan_four_step_golden(ksa, tag):
-    """N > 16384 runs the two-kernel four-step path; config 5 geometry (65536, 75 % overlap, 29 windows)."""
+    """16384 < N <= 262144 runs the radix-16 DIF stage in front of the single-workgroup kernel (path 2; larger N the
+    four-step kernels, path 1); config 5 geometry (65536, 75 % overlap, 29 windows)."""
     g = golden("curscan_" + tag)
     n, q, full = int(g["fft_size"]), float(g["non_overlap"]), int(g["full"])
     x = orc.synth_iq(full, int(g["seed"])).astype(np.complex64)
     for mode, key, dec in (("AVG", "avg_at_idx", "avg_decim"), ("MAX", "max_at_idx", "max_decim")):
         eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=str(g["window"]), cumu_mode=mode)
-        assert eng.kernel_info()["path"] == 1
+        assert eng.kernel_info()["path"] == 2
         y = eng.curscan(x)
         peak = float(g["peak"])
         assert np.max(np.abs(y[g["idx"]] - g[key])) / peak <= 1e-5
