@@ -15,6 +15,7 @@
 #include "ksa_dif16.hpp"
 #include "ksa_fourstep.hpp"
 #include "ksa_kernels.hpp"
+#include "ksa_kernels32.hpp"
 
 namespace {
 
@@ -112,6 +113,7 @@ struct ksa_engine {
   // launch config of the spectrum kernel
   int path = 0, threads = 0, lds_bytes = 0, vgprs = 0, blocks_per_cu = 1;
   int reuse_m = 0;              // new samples per thread per window when hops are a fixed multiple of N/16
+  bool plan32 = false;          // 8192 / 16384: the 32-points-per-thread kernel (ksa_kernels32.hpp)
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -195,9 +197,57 @@ int launch_spec_rm(ksa_engine* e, const SpecParams& p, bool cfg_only, int rm) {
   return launch_spec_t<N, FMT, 0>(e, p, cfg_only);
 }
 
+// 32 points per thread (N = 8192, 16384): fold mode always a template constant
+template <int N, int FMT, int CM>
+int launch_spec32_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
+  using P = ksa::Plan32<N>;
+  auto kfn = ksa::spectrum32_kernel<N, FMT, CM>;
+  if (configure_only) {
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES));
+    hipFuncAttributes attr;
+    HIP_OK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kfn)));
+    int occ = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, P::T, P::LDS_BYTES));
+    if (FMT == ksa::FMT_C64 && CM == ksa::CUMU_AVG) {
+      e->threads = P::T;
+      e->lds_bytes = P::LDS_BYTES;
+      e->vgprs = attr.numRegs;
+      e->blocks_per_cu = std::max(1, occ);
+    }
+    return 0;
+  }
+  const int capacity = e->num_cu * e->blocks_per_cu;
+  SpecParams q = p;
+  if (e->d_parts && !getenv("KSA_NO_SPLIT") && p.nwin > 1 && p.nframes * 2 <= capacity) {   // window-split (latency) mode
+    q.parts = std::min(p.nwin, capacity / p.nframes);
+    q.part_out = e->d_parts;
+  }
+  const int grid = std::max(1, std::min(q.nframes * std::max(1, q.parts), capacity));
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), P::LDS_BYTES, e->stream, q);
+  if (q.parts > 1) {
+    hipLaunchKernelGGL(ksa::combine_parts_kernel, dim3((N / 4 + 63) / 64, q.nframes), dim3(64), 0, e->stream, q, N);
+    if (q.hm_w > 0)
+      hipLaunchKernelGGL(ksa::rowmax_batch, dim3((q.hm_w + 255) / 256, q.nframes), dim3(256), 0, e->stream, q, N);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template <int N, int FMT>
+int launch_spec32(ksa_engine* e, const SpecParams& p, bool cfg_only) {
+  if (cfg_only) {
+    if (launch_spec32_c<N, FMT, ksa::CUMU_MAX>(e, p, true) || launch_spec32_c<N, FMT, ksa::CUMU_MIN>(e, p, true)) return 1;
+    return launch_spec32_c<N, FMT, ksa::CUMU_AVG>(e, p, true);
+  }
+  if (p.cumu == ksa::CUMU_AVG) return launch_spec32_c<N, FMT, ksa::CUMU_AVG>(e, p, false);
+  if (p.cumu == ksa::CUMU_MAX) return launch_spec32_c<N, FMT, ksa::CUMU_MAX>(e, p, false);
+  return launch_spec32_c<N, FMT, ksa::CUMU_MIN>(e, p, false);
+}
+
 template <int FMT>
 int launch_spec_n(ksa_engine* e, const SpecParams& p, bool cfg_only) {
   const int rm = p.nwin > 1 ? e->reuse_m : 0;   // RAW mode transforms a single window: nothing to reuse
+  if (e->plan32) return e->sub_n == 8192 ? launch_spec32<8192, FMT>(e, p, cfg_only) : launch_spec32<16384, FMT>(e, p, cfg_only);
   switch (e->sub_n) {
     case 16: return launch_spec_rm<16, FMT>(e, p, cfg_only, rm);
     case 32: return launch_spec_rm<32, FMT>(e, p, cfg_only, rm);
@@ -499,7 +549,40 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     const int r0 = 1 << (log2n - lpt * (m - 1));
     std::vector<float2> mid, last;
     int pcur = r0;
-    for (int s = 1; s < m; ++s) {
+    e->plan32 = (sn == 8192 || sn == 16384) && !getenv("KSA_PLAN16");   // KSA_PLAN16: A/B switch back to the 16-point plan
+    if (e->plan32) {
+      // folded twiddles of dft16_fused for a base twiddle of `beta` turns: w^4, w^8, w^12, then w^n2 * W16^(n2*k1)
+      auto fused15 = [](double beta, int e) {
+        double turns;
+        if (e < 3) turns = 4.0 * (e + 1) * beta;
+        else { const int k1 = (e - 3) / 3, n2 = (e - 3) % 3 + 1; turns = n2 * beta + (double)(n2 * k1) / 16.0; }
+        const double ang = -2.0 * M_PI * turns;
+        return make_float2((float)std::cos(ang), (float)std::sin(ang));
+      };
+      const int r1 = sn == 16384 ? 32 : 16, lth = sn / 32;
+      if (r1 == 32) {          // middle pass radix 32, p = 32: [31][32] = w^16 | fused15(k/1024) | fused15(k/1024 + 1/32)
+        mid.resize((size_t)31 * 32);
+        for (int k = 0; k < 32; ++k) {
+          const double beta = (double)k / 1024.0;
+          const double a16 = -2.0 * M_PI * 16.0 * beta;
+          mid[k] = make_float2((float)std::cos(a16), (float)std::sin(a16));
+          for (int ee = 0; ee < 15; ++ee) {
+            mid[(size_t)(1 + ee) * 32 + k] = fused15(beta, ee);
+            mid[(size_t)(16 + ee) * 32 + k] = fused15(beta + 1.0 / 32.0, ee);
+          }
+        }
+      } else {                 // middle pass radix 16, p = 32: [15][32] = fused15(k/512)
+        mid.resize((size_t)15 * 32);
+        for (int k = 0; k < 32; ++k)
+          for (int ee = 0; ee < 15; ++ee) mid[(size_t)ee * 32 + k] = fused15((double)k / 512.0, ee);
+      }
+      // last pass radix 16, two butterflies per thread, k = i = l + b*L: [(b*15 + e)][L]
+      last.resize((size_t)30 * lth);
+      for (int b = 0; b < 2; ++b)
+        for (int ee = 0; ee < 15; ++ee)
+          for (int l = 0; l < lth; ++l) last[(size_t)(b * 15 + ee) * lth + l] = fused15((double)(l + b * lth) / (double)sn, ee);
+    }
+    for (int s = 1; s < m && !e->plan32; ++s) {
       std::vector<float2>& dst = s < m - 1 ? mid : last;
       const bool fused = s < m - 1 ? fused_mid : fused_last;
       if (fused) {

@@ -36,6 +36,15 @@ __device__ __forceinline__ float2 mul_w16(float2 v) {
   else { static_assert(M < 0, "unsupported W16 exponent"); return v; }
 }
 
+// v *= W16^M for any M in 0..7 (general constant form where mul_w16 has no special case)
+template <int M>
+__device__ __forceinline__ float2 mul_w16_any(float2 v) {
+  if constexpr (M == 0 || M == 1 || M == 2 || M == 3 || M == 4 || M == 6) return mul_w16<M>(v);
+  else if constexpr (M == 5) return cmul(v, make_float2(-kSinPi8, -kCosPi8));
+  else if constexpr (M == 7) return cmul(v, make_float2(-kCosPi8, -kSinPi8));
+  else { static_assert(M < 0, "unsupported W16 exponent"); return v; }
+}
+
 template <int BASE, int STRIDE, int SZ>
 __device__ __forceinline__ void dft2(float2 (&v)[SZ]) {
   float2 a = v[BASE], b = v[BASE + STRIDE];
@@ -162,6 +171,111 @@ __device__ __forceinline__ void dft16_fused(float2 (&v)[16], const float2 (&tw)[
   dft4_tw<8, 1>(v, tw[9], tw[10], tw[11]);
   dft4_tw<12, 1>(v, tw[12], tw[13], tw[14]);
 }
+
+// ---- 32 points per thread (ksa_kernels32.hpp) -----------------------------------------------------------
+// The radix-16 forms above on a 16-element slice v[BASE .. BASE+15] of a larger register array.
+template <int BASE, int SZ>
+__device__ __forceinline__ void dft16_at(float2 (&v)[SZ]) {
+  dft4<BASE + 0, 4>(v);
+  dft4<BASE + 1, 4>(v);
+  dft4<BASE + 2, 4>(v);
+  dft4<BASE + 3, 4>(v);
+  v[BASE + 5] = mul_w16<1>(v[BASE + 5]);
+  v[BASE + 6] = mul_w16<2>(v[BASE + 6]);
+  v[BASE + 7] = mul_w16<3>(v[BASE + 7]);
+  v[BASE + 9] = mul_w16<2>(v[BASE + 9]);
+  v[BASE + 10] = mul_w16<4>(v[BASE + 10]);
+  v[BASE + 11] = mul_w16<6>(v[BASE + 11]);
+  v[BASE + 13] = mul_w16<3>(v[BASE + 13]);
+  v[BASE + 14] = mul_w16<6>(v[BASE + 14]);
+  v[BASE + 15] = mul_w16<9>(v[BASE + 15]);
+  dft4<BASE + 0, 1>(v);
+  dft4<BASE + 4, 1>(v);
+  dft4<BASE + 8, 1>(v);
+  dft4<BASE + 12, 1>(v);
+}
+
+// radix-16 of (w^t * v[BASE+t]) with all 15 twiddles folded into the radix-4 levels (layout of dft16_fused)
+template <int BASE, int SZ>
+__device__ __forceinline__ void dft16_fused_at(float2 (&v)[SZ], const float2 (&tw)[15]) {
+  dft4_tw<BASE + 0, 4>(v, tw[0], tw[1], tw[2]);
+  dft4_tw<BASE + 1, 4>(v, tw[0], tw[1], tw[2]);
+  dft4_tw<BASE + 2, 4>(v, tw[0], tw[1], tw[2]);
+  dft4_tw<BASE + 3, 4>(v, tw[0], tw[1], tw[2]);
+  dft4_tw<BASE + 0, 1>(v, tw[3], tw[4], tw[5]);
+  dft4_tw<BASE + 4, 1>(v, tw[6], tw[7], tw[8]);
+  dft4_tw<BASE + 8, 1>(v, tw[9], tw[10], tw[11]);
+  dft4_tw<BASE + 12, 1>(v, tw[12], tw[13], tw[14]);
+}
+
+// radix-16 of (w^t * v[BASE+t]) from six twiddles (layout of dft16_tw: w^1, w^2, w^3, w^4, w^8, w^12)
+template <int BASE, int SZ>
+__device__ __forceinline__ void dft16_tw_at(float2 (&v)[SZ], float2 w1, float2 w2, float2 w3, float2 w4, float2 w8, float2 w12) {
+  dft4_tw<BASE + 0, 4>(v, w4, w8, w12);
+  dft4_tw<BASE + 1, 4>(v, w4, w8, w12);
+  dft4_tw<BASE + 2, 4>(v, w4, w8, w12);
+  dft4_tw<BASE + 3, 4>(v, w4, w8, w12);
+  dft4_tw<BASE + 0, 1>(v, w1, w2, w3);
+  v[BASE + 5] = mul_w16<1>(v[BASE + 5]);
+  v[BASE + 6] = mul_w16<2>(v[BASE + 6]);
+  v[BASE + 7] = mul_w16<3>(v[BASE + 7]);
+  dft4_tw<BASE + 4, 1>(v, w1, w2, w3);
+  v[BASE + 9] = mul_w16<2>(v[BASE + 9]);
+  v[BASE + 10] = mul_w16<4>(v[BASE + 10]);
+  v[BASE + 11] = mul_w16<6>(v[BASE + 11]);
+  dft4_tw<BASE + 8, 1>(v, w1, w2, w3);
+  v[BASE + 13] = mul_w16<3>(v[BASE + 13]);
+  v[BASE + 14] = mul_w16<6>(v[BASE + 14]);
+  v[BASE + 15] = mul_w16<9>(v[BASE + 15]);
+  dft4_tw<BASE + 12, 1>(v, w1, w2, w3);
+}
+
+// v *= W32^M, the exponents the first (radix-2) level of a 32-point butterfly needs (M = 1..15)
+template <int M>
+__device__ __forceinline__ float2 mul_w32(float2 v) {
+  if constexpr (M % 2 == 0) return mul_w16_any<M / 2>(v);
+  else {
+    constexpr float c[8] = {0.98078528040323044913f, 0.83146961230254523708f, 0.55557023301960222474f, 0.19509032201612826785f,
+                            -0.19509032201612826785f, -0.55557023301960222474f, -0.83146961230254523708f, -0.98078528040323044913f};
+    constexpr float s[8] = {0.19509032201612826785f, 0.55557023301960222474f, 0.83146961230254523708f, 0.98078528040323044913f,
+                            0.98078528040323044913f, 0.83146961230254523708f, 0.55557023301960222474f, 0.19509032201612826785f};
+    return cmul(v, make_float2(c[M / 2], -s[M / 2]));   // e^{-2 pi i M/32}
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void unroll_w32(float2 (&v)[32]) {
+  if constexpr (T < 16) {
+    const float2 a = v[T], b = v[T + 16];
+    v[T] = cadd(a, b);
+    if constexpr (T == 0) v[T + 16] = csub(a, b);
+    else v[T + 16] = mul_w32<T>(csub(a, b));
+    unroll_w32<T + 1>(v);
+  }
+}
+
+// 32-point butterfly, natural order in, position P ends up holding X[perm32(P)] = X[2*perm16(P & 15) + (P >> 4)]:
+// one radix-2 level (decimation in frequency) in front of two radix-16.
+__device__ __forceinline__ void dft32(float2 (&v)[32]) {
+  unroll_w32<0>(v);
+  dft16_at<0>(v);
+  dft16_at<16>(v);
+}
+
+// 32-point butterfly of (w^t * v[t]): the radix-2 level takes w^16, the two radix-16 take the folded twiddles of
+// base w (even outputs) and of base w * W32 (odd outputs).
+__device__ __forceinline__ void dft32_fused(float2 (&v)[32], float2 w16, const float2 (&twa)[15], const float2 (&twb)[15]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const float2 s = cfma(v[t], w16, v[t + 16]);     // v[t] + w^16 * v[t+16]
+    v[t + 16] = twice_minus(v[t], s);                // v[t] - w^16 * v[t+16]
+    v[t] = s;
+  }
+  dft16_fused_at<0>(v, twa);
+  dft16_fused_at<16>(v, twb);
+}
+
+__host__ __device__ constexpr int perm32(int p) { return 2 * (((p & 15) >> 2) | ((p & 3) << 2)) + (p >> 4); }
 
 // output index held at register position P after the in-place transforms above
 template <int R>
