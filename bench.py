@@ -368,7 +368,11 @@ def main():
         tflops = units_per_step * nwin * algorithmic_flops_per_fft(n) / avg_kernel_s / 1e12
         step_s = dt / args.steps
         if info["path"] == 1:
-            kernel = "ksa four-step path (column + row kernels, N = N1*N2 through HBM/L2 scratch)"
+            kernel = "ksa::fourstep_cols + ksa::fourstep_rows (N = N1*N2 through HBM scratch)"
+        elif info["path"] == 2:
+            kernel = "ksa::dif16_kernel<%s> + ksa::spectrum_kernel<%d,c64> + ksa::dif16_finish_kernel (N = 16*%d)" % (args.fmt, n // 16, n // 16)
+        elif info["path"] == 3:
+            kernel = "ksa::spectrum32_kernel<%d,%s>" % (n, args.fmt)
         else:
             kernel = "ksa::spectrum_kernel<%d,%s>" % (n, args.fmt)
         key = "%d:%s:%d" % (args.config, args.fmt, units_per_step)

@@ -1084,7 +1084,7 @@ int ksa_kernel_info(ksa_engine* e, int32_t* threads, int32_t* lds_bytes, int32_t
   if (lds_bytes) *lds_bytes = e->lds_bytes;
   if (vgprs) *vgprs = e->vgprs;
   if (grid) *grid = e->num_cu * e->blocks_per_cu;
-  if (path) *path = e->path;
+  if (path) *path = (e->path == 0 && e->plan32) ? 3 : e->path;
   return 0;
 }
 

@@ -698,27 +698,45 @@ __global__ void scan_stitch_kernel(const StitchParams p) {
   const bool covered = i0 <= i1;       // not covered: the state keeps its value
   const int tot = p.total;
   float cur = p.state[e], mx = p.state[tot + e], mn = p.state[2 * tot + e], av = p.state[3 * tot + e];
-  for (int ps = 0; ps < p.npasses; ++ps) {
-    if (covered) {
-      const float* db = p.step_db + (long long)ps * p.nsteps * p.n;
-      const bool first = p.first_pass && ps == 0;
-      cur = db[(long long)i0 * p.n + (e - i0 * p.hop)];
-      for (int i = i0 + 1; i <= i1; ++i) cur = (cur + db[(long long)i * p.n + (e - i * p.hop)]) * 0.5f;
-      if (!p.base_is_raw) {
-        if (p.b_max) mx = nan_max(mx, cur);
-        if (p.b_min) mn = nan_min(mn, cur);
-        av = first ? cur : (av + cur) * 0.5f;
-      } else {
-        // every covering step, in order, folds its own spectrum in (pass 0: Avg is overwritten by each step)
-        for (int i = i0; i <= i1; ++i) {
-          const float x = db[(long long)i * p.n + (e - i * p.hop)];
-          if (p.b_max) mx = nan_max(mx, x);
-          if (p.b_min) mn = nan_min(mn, x);
-          av = first ? x : (av + x) * 0.5f;
+  // stitched value of this element in pass ps (K:643-650): the first covering step raw, every later one halved in
+  auto stitched = [&](int ps) {
+    const float* db = p.step_db + (long long)ps * p.nsteps * p.n;
+    float c = db[(long long)i0 * p.n + (e - i0 * p.hop)];
+    for (int i = i0 + 1; i <= i1; ++i) c = (c + db[(long long)i * p.n + (e - i * p.hop)]) * 0.5f;
+    return c;
+  };
+  constexpr int AHEAD = 8;   // passes whose loads are in flight per thread (a batch has few elements but many passes)
+  float nxt[AHEAD];
+  for (int ps0 = 0; ps0 < p.npasses; ps0 += AHEAD) {
+    if (covered && !p.base_is_raw) {
+#pragma unroll
+      for (int u = 0; u < AHEAD; ++u) nxt[u] = ps0 + u < p.npasses ? stitched(ps0 + u) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) {
+      const int ps = ps0 + u;
+      if (ps >= p.npasses) break;
+      if (covered) {
+        const bool first = p.first_pass && ps == 0;
+        if (!p.base_is_raw) {
+          cur = nxt[u];
+          if (p.b_max) mx = nan_max(mx, cur);
+          if (p.b_min) mn = nan_min(mn, cur);
+          av = first ? cur : (av + cur) * 0.5f;
+        } else {
+          // every covering step, in order, folds its own spectrum in (pass 0: Avg is overwritten by each step)
+          cur = stitched(ps);
+          const float* db = p.step_db + (long long)ps * p.nsteps * p.n;
+          for (int i = i0; i <= i1; ++i) {
+            const float x = db[(long long)i * p.n + (e - i * p.hop)];
+            if (p.b_max) mx = nan_max(mx, x);
+            if (p.b_min) mn = nan_min(mn, x);
+            av = first ? x : (av + x) * 0.5f;
+          }
         }
       }
+      if (p.avg_rows && ps >= p.avg_row0) p.avg_rows[(long long)(ps - p.avg_row0) * tot + e] = av;
     }
-    if (p.avg_rows && ps >= p.avg_row0) p.avg_rows[(long long)(ps - p.avg_row0) * tot + e] = av;
   }
   if (covered) {
     p.state[e] = cur;
