@@ -72,6 +72,14 @@ def test_random_configuration(ksa, case):
         assert_db(st["Fft.Avg"], st_ref.avg, what="avg")
     elif well.any():
         assert_db(st["Fft.Avg"][well], st_ref.avg[well], what="avg (well-conditioned bins)")
+    # every bin, ill-conditioned ones included: the NaN pattern is the reference's, and an EMA of the frames' dB
+    # values lies between their minimum and maximum (a -inf frame poisons Min and Avg alike, K:469)
+    avg, mx, mn = st["Fft.Avg"], st["Fft.Max"], st["Fft.Min"]
+    assert np.array_equal(np.isnan(avg), np.isnan(st_ref.avg)), "avg NaN pattern"
+    ok = ~np.isnan(avg)
+    assert not np.isposinf(avg[ok]).any()
+    assert np.all(avg[ok] <= mx[ok] + 1e-3) and np.all(avg[ok] >= mn[ok] - 1e-3), "avg outside [min, max]"
+    assert np.array_equal(np.isneginf(avg), np.isneginf(mn)), "-inf pattern of avg and min differ"
     rows = min(frames, 128)
     assert_db(st["fftHM"][:rows], st_ref.hm[:rows], what="waterfall")
     # the host-pointer drop-in agrees with the batched path
