@@ -371,6 +371,8 @@ def main():
             kernel = "ksa::fourstep_cols + ksa::fourstep_rows (N = N1*N2 through HBM scratch)"
         elif info["path"] == 2:
             kernel = "ksa::dif16_kernel<%s> + ksa::spectrum_kernel<%d,c64> + ksa::dif16_finish_kernel (N = 16*%d)" % (args.fmt, n // 16, n // 16)
+        elif info["path"] == 4:
+            kernel = "ksa::spectrum_pair_kernel<%d,%s> (two frames per workgroup, packed fp32)" % (n, args.fmt)
         elif info["path"] == 3:
             kernel = "ksa::spectrum32_kernel<%d,%s>" % (n, args.fmt)
         else:

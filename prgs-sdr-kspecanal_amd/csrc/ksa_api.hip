@@ -16,6 +16,7 @@
 #include "ksa_fourstep.hpp"
 #include "ksa_kernels.hpp"
 #include "ksa_kernels32.hpp"
+#include "ksa_kernels_pair.hpp"
 
 namespace {
 
@@ -114,6 +115,9 @@ struct ksa_engine {
   int path = 0, threads = 0, lds_bytes = 0, vgprs = 0, blocks_per_cu = 1;
   int reuse_m = 0;              // new samples per thread per window when hops are a fixed multiple of N/16
   bool plan32 = false;          // 8192 / 16384: the 32-points-per-thread kernel (ksa_kernels32.hpp)
+  // 1024 .. 4096, large batches: two frames per workgroup in packed fp32 (ksa_kernels_pair.hpp)
+  bool pair_ok = false;
+  int pair_bpc = 0, pair_vgprs = 0, pair_lds = 0;
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -128,8 +132,50 @@ using ksa::SpecParams;
 template <int N, int FMT, int RM, int CM>
 int launch_spec_c(ksa_engine* e, const SpecParams& p, bool configure_only);
 
+template <int N, int FMT, int RM, int CM>
+int launch_pair_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
+  using PP = ksa::PlanPair<N>;
+  auto kfn = ksa::spectrum_pair_kernel<N, FMT, RM, CM>;
+  if (configure_only) {
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS_BYTES));
+    hipFuncAttributes attr;
+    HIP_OK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kfn)));
+    int occ = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, ksa::Plan<N>::T, PP::LDS_BYTES));
+    if (FMT == ksa::FMT_C64 && CM == ksa::CUMU_AVG) {
+      e->pair_bpc = std::max(1, occ);
+      e->pair_vgprs = attr.numRegs;
+      e->pair_lds = PP::LDS_BYTES;
+    }
+    return 0;
+  }
+  const int npairs = (p.nframes + 1) / 2;
+  const int grid = std::max(1, std::min(npairs, e->num_cu * e->pair_bpc));
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(ksa::Plan<N>::T), PP::LDS_BYTES, e->stream, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template <int N, int FMT, int RM>
+int launch_pair(ksa_engine* e, const SpecParams& p, bool cfg_only) {
+  if (cfg_only) {
+    if (launch_pair_c<N, FMT, RM, ksa::CUMU_MAX>(e, p, true) || launch_pair_c<N, FMT, RM, ksa::CUMU_MIN>(e, p, true)) return 1;
+    return launch_pair_c<N, FMT, RM, ksa::CUMU_AVG>(e, p, true);
+  }
+  if (p.cumu == ksa::CUMU_AVG) return launch_pair_c<N, FMT, RM, ksa::CUMU_AVG>(e, p, false);
+  if (p.cumu == ksa::CUMU_MAX) return launch_pair_c<N, FMT, RM, ksa::CUMU_MAX>(e, p, false);
+  return launch_pair_c<N, FMT, RM, ksa::CUMU_MIN>(e, p, false);
+}
+
 template <int N, int FMT, int RM>
 int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
+  // large batches of 1024 .. 4096-point transforms: two frames per workgroup in packed fp32
+  if constexpr (ksa::Plan<N>::S == 1 && ksa::Plan<N>::T <= 256 && ksa::Plan<N>::M >= 2) {
+    if (e->pair_ok) {
+      if (configure_only) { if (launch_pair<N, FMT, RM>(e, p, true)) return 1; }
+      else if (p.nframes >= 2 * e->num_cu * e->pair_bpc) return launch_pair<N, FMT, RM>(e, p, false);
+    }
+  }
   // fold mode as a template constant (Tune<N>::fold_const) or as a run-time branch inside the window loop
   if constexpr (ksa::Tune<N>::fold_const(RM)) {
     if (configure_only) {
@@ -222,7 +268,8 @@ int launch_spec32_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
     q.parts = std::min(p.nwin, capacity / p.nframes);
     q.part_out = e->d_parts;
   }
-  const int grid = std::max(1, std::min(q.nframes * std::max(1, q.parts), capacity));
+  int grid = std::max(1, std::min(q.nframes * std::max(1, q.parts), capacity));
+  if (const char* g = getenv("KSA_GRID")) grid = std::max(1, std::min(grid, atoi(g)));   // measurement: fewer persistent workgroups
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), P::LDS_BYTES, e->stream, q);
   if (q.parts > 1) {
     hipLaunchKernelGGL(ksa::combine_parts_kernel, dim3((N / 4 + 63) / 64, q.nframes), dim3(64), 0, e->stream, q, N);
@@ -550,6 +597,10 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     std::vector<float2> mid, last;
     int pcur = r0;
     e->plan32 = (sn == 8192 || sn == 16384) && !getenv("KSA_PLAN16");   // KSA_PLAN16: A/B switch back to the 16-point plan
+    // Two frames per workgroup in packed fp32 (ksa_kernels_pair.hpp).  Measured against the one-frame kernel on MI355X
+    // (tools/pair_sweep.sh, hops 0.5 / 0.25 / 0.1): N = 1024 +14..+30 %, N = 2048 -3..-5 %, N = 4096 0..-5 % -- on by
+    // default for 1024 only.  KSA_PAIR_ALL enables it for 1024 .. 4096, KSA_NO_PAIR disables it (A/B switches).
+    e->pair_ok = !getenv("KSA_NO_PAIR") && (sn == 1024 || (getenv("KSA_PAIR_ALL") && sn >= 1024 && sn <= 4096));
     if (e->plan32) {
       // folded twiddles of dft16_fused for a base twiddle of `beta` turns: w^4, w^8, w^12, then w^n2 * W16^(n2*k1)
       auto fused15 = [](double beta, int e) {
@@ -1084,7 +1135,12 @@ int ksa_kernel_info(ksa_engine* e, int32_t* threads, int32_t* lds_bytes, int32_t
   if (lds_bytes) *lds_bytes = e->lds_bytes;
   if (vgprs) *vgprs = e->vgprs;
   if (grid) *grid = e->num_cu * e->blocks_per_cu;
-  if (path) *path = (e->path == 0 && e->plan32) ? 3 : e->path;
+  if (path) *path = (e->path == 0 && e->plan32) ? 3 : (e->path == 0 && e->pair_ok) ? 4 : e->path;
+  if (e->path == 0 && e->pair_ok) {           // what large batches run
+    if (lds_bytes) *lds_bytes = e->pair_lds;
+    if (vgprs) *vgprs = e->pair_vgprs;
+    if (grid) *grid = e->num_cu * e->pair_bpc;
+  }
   return 0;
 }
 

@@ -150,7 +150,14 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define KSA_LDS_ST(dst, val) do {} while (0)
 #define KSA_LDS_LD(dst, src) do {} while (0)
 #else
+// Exchange barriers of the window loop.  __syncthreads() also waits for every outstanding global access
+// (s_waitcnt vmcnt(0)): after a frame's output stage that means the first exchange of the next frame stalls until the
+// frame's dB row has reached memory.  The LDS-only form orders what the exchanges need (LDS) and lets stores drain.
+#ifdef KSA_LDS_BARRIER
+#define KSA_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
 #define KSA_SYNC() __syncthreads()
+#endif
 #define KSA_LDS_ST(dst, val) (dst) = (val)
 #define KSA_LDS_LD(dst, src) (dst) = (src)
 #endif

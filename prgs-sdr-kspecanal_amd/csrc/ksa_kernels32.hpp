@@ -44,7 +44,7 @@ __host__ __device__ constexpr int pad32(int i) { return i + (i >> 5); }
 //                                                                     inside the window loop)
 // The -D overrides are for tools/variants.sh only.
 #ifndef KSA32_PREFETCH
-#define KSA32_PREFETCH 0   // 1: issue the next window's IQ loads during this window's transform (after the middle pass)
+#define KSA32_PREFETCH 0   // 1: issue the next window's IQ loads during this window's transform (after the middle pass); 2: and its taps
 #endif
 #ifndef KSA32_TW6
 #define KSA32_TW6 1        // last pass from 6 twiddles per butterfly (24 VGPRs) instead of 15 folded ones (60 VGPRs)
@@ -56,12 +56,23 @@ __host__ __device__ constexpr int pad32(int i) { return i + (i >> 5); }
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load
 // (s_waitcnt vmcnt(0)), which would drain the prefetched IQ loads at the first exchange of every window.
 __device__ __forceinline__ void lds_barrier() {
+#ifdef KSA32_ABL_NOLDS     // timing-only ablation build (no exchange): wrong results by construction
+  return;
+#endif
 #if KSA32_PREFETCH
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
   __syncthreads();
 #endif
 }
+
+#ifdef KSA32_ABL_NOLDS
+#define K32_ST(dst, val) do {} while (0)
+#define K32_LD(dst, src) do {} while (0)
+#else
+#define K32_ST(dst, val) (dst) = (val)
+#define K32_LD(dst, src) (dst) = (src)
+#endif
 
 template <int N, int FMT, int CM>
 __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kernel(const SpecParams p) {
@@ -99,7 +110,11 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
   auto load_taps = [&]() {
 #pragma unroll
     for (int q = 0; q < 32; ++q)
+#ifdef KSA32_ABL_NOLOAD
+      win[q] = (float)(l + q) * p.u8_inv_scale;
+#else
       win[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, l * 4, L * q * 4, 0)) * (FMT == FMT_U8 ? p.u8_inv_scale : 1.0f);
+#endif
   };
   if constexpr (KSA32_WIN_REGS) load_taps();
 
@@ -113,8 +128,13 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
     const int voff = (p.starts[k] + l) * SB;
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
+#ifdef KSA32_ABL_NOLOAD    // timing-only ablation build: wrong results by construction
+      if constexpr (FMT == FMT_C64) { raw[q].x = voff + q; raw[q].y = voff * q; }
+      else raw[q] = voff + q;
+#else
       if constexpr (FMT == FMT_C64) raw[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, L * q * SB, 0);
       else raw[q] = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, L * q * SB, 0);
+#endif
     }
   };
   auto k_lo_of = [&](int vf) { return (int)((long long)p.nwin * (vf % NP) / NP); };
@@ -129,6 +149,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
     if constexpr (KSA32_PREFETCH) {                          \
       __builtin_amdgcn_sched_barrier(0);                     \
       issue_loads(vf, k + 1 < k_hi ? k + 1 : k);             \
+      if constexpr (KSA32_PREFETCH == 2) load_taps();        \
       __builtin_amdgcn_sched_barrier(0);                     \
     }                                                        \
   } while (0)
@@ -141,11 +162,12 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = init;
     if constexpr (KSA32_PREFETCH) issue_loads(vf, k_lo);
+    if constexpr (KSA32_PREFETCH == 2) load_taps();
 
     for (int k = k_lo; k < k_hi; ++k) {
       // ---- samples of window (vf, k): window multiply (rows A0, A4) ------------------------------------
       if constexpr (!KSA32_PREFETCH) issue_loads(vf, k);
-      if constexpr (!KSA32_WIN_REGS) load_taps();
+      if constexpr (!KSA32_WIN_REGS && KSA32_PREFETCH != 2) load_taps();
       float2 v[32];
 #pragma unroll
       for (int q = 0; q < 32; ++q) {
@@ -161,11 +183,11 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
       dft32(v);
       lds_barrier();   // the previous window's (frame's) LDS reads are done
 #pragma unroll
-      for (int P0 = 0; P0 < 32; ++P0) my[pad32(l * 32 + perm32(P0))] = v[P0];
+      for (int P0 = 0; P0 < 32; ++P0) K32_ST(my[pad32(l * 32 + perm32(P0))], v[P0]);
       lds_barrier();
       // ---- pass 1: p = 32, k = l mod 32 ---------------------------------------------------------------
 #pragma unroll
-      for (int q = 0; q < 32; ++q) v[(q % B1) * R1 + q / B1] = my[pad32(l + L * q)];
+      for (int q = 0; q < 32; ++q) K32_LD(v[(q % B1) * R1 + q / B1], my[pad32(l + L * q)]);
       {
         const int kk = l & 31;
         const float2* tw = tw_lds + kk;
@@ -174,52 +196,56 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
 #pragma unroll
           for (int e = 0; e < 15; ++e) { ta[e] = tw[(1 + e) * 32]; tb[e] = tw[(16 + e) * 32]; }
           dft32_fused(v, tw[0], ta, tb);
-          PREFETCH_NEXT();
           lds_barrier();
           const int j = (l - kk) * 32 + kk;
 #pragma unroll
-          for (int P1 = 0; P1 < 32; ++P1) my[pad32(j + perm32(P1) * 32)] = v[P1];
+          for (int P1 = 0; P1 < 32; ++P1) K32_ST(my[pad32(j + perm32(P1) * 32)], v[P1]);
         } else {
           float2 tm[15];
 #pragma unroll
           for (int e = 0; e < 15; ++e) tm[e] = tw[e * 32];
           dft16_fused_at<0>(v, tm);      // i = l      (k = l mod 32)
           dft16_fused_at<16>(v, tm);     // i = l + L  (L is a multiple of 32: same k)
-          PREFETCH_NEXT();
           lds_barrier();
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             const int j = (l + b * L - kk) * 16 + kk;
 #pragma unroll
-            for (int P1 = 0; P1 < 16; ++P1) my[pad32(j + perm<16>(P1) * 32)] = v[b * 16 + P1];
+            for (int P1 = 0; P1 < 16; ++P1) K32_ST(my[pad32(j + perm<16>(P1) * 32)], v[b * 16 + P1]);
           }
         }
       }
+      PREFETCH_NEXT();   // v is dead (written to LDS): the landing registers are free from here to the next window's top
       lds_barrier();
-      // ---- pass 2: radix 16, p = N/16, butterflies i = l + b*L with k = i -----------------------------
-#pragma unroll
-      for (int q = 0; q < 32; ++q) v[(q % 2) * 16 + q / 2] = my[pad32(l + L * q)];
-      if constexpr (KSA32_TW6) {
-        dft16_tw_at<0>(v, twl[0][0], twl[0][1], twl[0][2], twl[0][3], twl[0][4], twl[0][5]);
-        dft16_tw_at<16>(v, twl[1][0], twl[1][1], twl[1][2], twl[1][3], twl[1][4], twl[1][5]);
-      } else {
-        dft16_fused_at<0>(v, reinterpret_cast<const float2(&)[15]>(twl[0]));
-        dft16_fused_at<16>(v, reinterpret_cast<const float2(&)[15]>(twl[1]));
-      }
-      // ---- |X| and the fold over this block's windows (K:391-395) ---------------------------------
+      // ---- pass 2: radix 16, p = N/16, butterflies i = l + b*L with k = i, one after the other (16 live data
+      //      registers instead of 32), each followed by |X| and the fold over this block's windows (K:391-395)
       const int cm = CM == 0 ? p.cumu : CM;
-      if (cm == CUMU_AVG) {
-        const int e = k == 0 ? nm1 : nm1 - k + 1;       // closed form of the (a+x)/2 recursion
-        const float w = ldexpf(1.0f, -e);
+      const int ew = k == 0 ? nm1 : nm1 - k + 1;         // closed form of the (a+x)/2 recursion: weight 2^-ew
+      const float wgt = ldexpf(1.0f, -ew);
 #pragma unroll
-        for (int i = 0; i < 32; ++i)
-          acc[i] = fmaf(w, __builtin_amdgcn_sqrtf(fmaf(v[i].x, v[i].x, v[i].y * v[i].y)), acc[i]);
-      } else if (cm == CUMU_MAX) {
+      for (int b = 0; b < 2; ++b) {
+        float2 u[16];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) acc[i] = fmaxf(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
-      } else {
+        for (int t = 0; t < 16; ++t) {
+#ifdef KSA32_ABL_NOLDS
+          u[t] = v[b * 16 + t];
+#else
+          u[t] = my[pad32(l + L * (b + 2 * t))];
+#endif
+        }
+        if constexpr (KSA32_TW6) dft16_tw_at<0>(u, twl[b][0], twl[b][1], twl[b][2], twl[b][3], twl[b][4], twl[b][5]);
+        else dft16_fused_at<0>(u, reinterpret_cast<const float2(&)[15]>(twl[b]));
+        if (cm == CUMU_AVG) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) acc[i] = fminf(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
+          for (int i = 0; i < 16; ++i)
+            acc[b * 16 + i] = fmaf(wgt, __builtin_amdgcn_sqrtf(fmaf(u[i].x, u[i].x, u[i].y * u[i].y)), acc[b * 16 + i]);
+        } else if (cm == CUMU_MAX) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[b * 16 + i] = fmaxf(acc[b * 16 + i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[b * 16 + i] = fminf(acc[b * 16 + i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
+        }
       }
     }
 
@@ -241,5 +267,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
 }
 
 #undef PREFETCH_NEXT
+#undef K32_ST
+#undef K32_LD
 
 }  // namespace ksa
