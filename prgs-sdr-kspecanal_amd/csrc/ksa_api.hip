@@ -975,7 +975,7 @@ static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int 
                        e->d_scan_state + (size_t)3 * s.total, e->d_scan_adj, c.scan_hm_width, g,
                        e->d_scan_hm + (size_t)e->scan_hm_index * c.scan_hm_width);
   } else {
-    hipLaunchKernelGGL(ksa::rowmax_rows_kernel, dim3((c.scan_hm_width + tb - 1) / tb, rows), dim3(tb), 0, e->stream,
+    hipLaunchKernelGGL(ksa::rowmax_rows_kernel, dim3(c.scan_hm_width, rows), dim3(64), 0, e->stream,
                        e->d_scan_avg_rows, e->d_scan_adj, c.scan_hm_width, g, e->d_scan_hm,
                        (e->scan_hm_index + s.avg_row0) % KSA_HM_ROWS);
   }

@@ -695,7 +695,7 @@ struct StitchParams {
 
 // One thread = one element of the stitched range, walking the passes of the batch in order: exactly the
 // sequence of updates the reference applies pass after pass, with the state in registers in between.
-__global__ void scan_stitch_kernel(const StitchParams p) {
+__global__ __launch_bounds__(256) void scan_stitch_kernel(const StitchParams p) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= p.total) return;
   int i0 = (e - p.n + p.hop) / p.hop;  // ceil((e-n+1)/hop) for e-n+1 > 0
@@ -712,18 +712,33 @@ __global__ void scan_stitch_kernel(const StitchParams p) {
     for (int i = i0 + 1; i <= i1; ++i) c = (c + db[(long long)i * p.n + (e - i * p.hop)]) * 0.5f;
     return c;
   };
-  constexpr int AHEAD = 8;   // passes whose loads are in flight per thread (a batch has few elements but many passes)
+  constexpr int AHEAD = 32;  // passes whose loads are in flight per thread (a batch has few elements but many passes)
   float nxt[AHEAD];
+  const int ncover = i1 - i0 + 1;                       // steps covering this element: 1 or 2 at the usual hop of N/2
+  const long long o0 = (long long)i0 * p.n + (e - i0 * p.hop), o1 = o0 + p.n - p.hop;
+  const long long pstride = (long long)p.nsteps * p.n;
   for (int ps0 = 0; ps0 < p.npasses; ps0 += AHEAD) {
     if (covered && !p.base_is_raw) {
+      if (ncover <= 2) {
+        // straight-line loads (no inner loop): all 2*AHEAD are in flight before the first is used
+        float a[AHEAD], b[AHEAD];
 #pragma unroll
-      for (int u = 0; u < AHEAD; ++u) nxt[u] = ps0 + u < p.npasses ? stitched(ps0 + u) : 0.f;
+        for (int u = 0; u < AHEAD; ++u) {
+          const bool in = ps0 + u < p.npasses;
+          a[u] = in ? p.step_db[(ps0 + u) * pstride + o0] : 0.f;
+          b[u] = in && ncover == 2 ? p.step_db[(ps0 + u) * pstride + o1] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) nxt[u] = ncover == 2 ? (a[u] + b[u]) * 0.5f : a[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) nxt[u] = ps0 + u < p.npasses ? stitched(ps0 + u) : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < AHEAD; ++u) {
       const int ps = ps0 + u;
-      if (ps >= p.npasses) break;
-      if (covered) {
+      if (covered && ps < p.npasses) {   // (no break: the loop must unroll fully, or nxt[] goes to scratch memory)
         const bool first = p.first_pass && ps == 0;
         if (!p.base_is_raw) {
           cur = nxt[u];
@@ -742,7 +757,7 @@ __global__ void scan_stitch_kernel(const StitchParams p) {
           }
         }
       }
-      if (p.avg_rows && ps >= p.avg_row0) p.avg_rows[(long long)(ps - p.avg_row0) * tot + e] = av;
+      if (p.avg_rows && ps >= p.avg_row0 && ps < p.npasses) p.avg_rows[(long long)(ps - p.avg_row0) * tot + e] = av;
     }
   }
   if (covered) {
@@ -854,20 +869,24 @@ __global__ void fill_kernel(float* dst, long long n, float v) {
 }
 
 // Scan waterfall rows of a batch of passes (K:696-697): row r of `src` ([rows][cells*g], Fft.Avg after a pass)
-// -> ring row (row0 + r) % 128.  blockIdx.y = r.
-__global__ void rowmax_rows_kernel(const float* src, const float* adj, int cells, int g, float* ring, int row0) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cells) return;
-  const float* row = src + (long long)blockIdx.y * cells * g;
+// -> ring row (row0 + r) % 128.  One wave per cell (lanes stride over the cell's g bins: coalesced), blockIdx.y = r.
+__global__ __launch_bounds__(64) void rowmax_rows_kernel(const float* src, const float* adj, int cells, int g, float* ring, int row0) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const float* row = src + (long long)blockIdx.y * cells * g + (long long)c * g;
+  const float* arow = adj ? adj + (long long)c * g : nullptr;
   float hv = -__builtin_inff();
-  bool nan = false;
-  for (int i = 0; i < g; ++i) {
-    float v = row[(long long)c * g + i];
-    if (adj) v -= adj[(long long)c * g + i];
+  int nan = 0;
+  for (int i = lane; i < g; i += 64) {
+    float v = row[i];
+    if (arow) v -= arow[i];
     nan |= v != v;
     hv = fmaxf(hv, v);
   }
-  ring[(long long)((row0 + blockIdx.y) % HM_ROWS) * cells + c] = nan ? __builtin_nanf("") : hv;
+  for (int m = 32; m >= 1; m >>= 1) {
+    hv = fmaxf(hv, __shfl_xor(hv, m));
+    nan |= __shfl_xor(nan, m);
+  }
+  if (lane == 0) ring[(long long)((row0 + blockIdx.y) % HM_ROWS) * cells + c] = nan ? __builtin_nanf("") : hv;
 }
 
 // out[c] = max_{i<g} (src[c*g+i] - adj[c*g+i])
