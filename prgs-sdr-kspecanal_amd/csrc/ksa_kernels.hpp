@@ -324,7 +324,11 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       const int k = k_lo + (S == 1 ? rd : rd * S + slot);   // wave-uniform when one transform fills the workgroup
       const bool active = S == 1 || k < k_hi;
       float2 v[16];
-      if (active) issue_loads(frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
+#ifndef KSA_PF
+#define KSA_PF 0   // 1 (reuse path only): the RM new samples of window k+1 are requested while window k is transformed
+#endif
+      if (KSA_PF && RM > 0) { if (rd == 0) issue_loads(frame, k, 0); }
+      else if (active) issue_loads(frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
       if (active) {
         if constexpr (!WIN_LDS && Tune<N>::WIN_GLOBAL) {
           // scalar descriptor + scalar offsets: no per-load address VGPRs
@@ -355,6 +359,9 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       }
       if (RM > 0) {
         shift_raw();   // the next round of this frame loads only its RM new samples
+        // prefetch: the freed registers take window k+1's new samples now (unconditionally: after the frame's last
+        // window the same samples are simply requested again), in flight under the three passes
+        if (KSA_PF) issue_loads(frame, k + 1 < k_hi ? k + 1 : k, 16 - RM);
       }
       KSA_STAMP(0);
       if (active) {
