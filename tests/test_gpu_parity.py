@@ -126,7 +126,7 @@ def test_curscan_four_step_golden(ksa, tag):
         eng.close()
 
 
-@pytest.mark.parametrize("n,q,fmt", [(32768, 0.5, "c64"), (65536, 0.25, "u8"), (131072, 0.5, "c64"), (1048576, 0.5, "c64")])
+@pytest.mark.parametrize("n,q,fmt", [(32768, 0.5, "c64"), (65536, 0.25, "u8"), (131072, 0.5, "c64"), (262144, 0.3, "u8"), (524288, 0.5, "c64"), (1048576, 0.5, "c64")])
 def test_four_step_full_spectrum_vs_oracle(ksa, n, q, fmt):
     full = 2 * n
     x = orc.synth_iq(full, 4000 + (n >> 10))
@@ -493,7 +493,7 @@ def test_merge_gathered_refusals(ksa, torch_cuda):
     eng.close()
 
 
-@pytest.mark.parametrize("n,xres", [(128, 64), (64, 64), (1024, 512), (4096, 16), (16384, 32), (16384, 8192), (256, 4), (65536, 64)])
+@pytest.mark.parametrize("n,xres", [(128, 64), (64, 64), (1024, 512), (4096, 16), (16384, 32), (16384, 8192), (256, 4), (65536, 64), (65536, 16), (32768, 32768), (131072, 2048)])
 def test_waterfall_cell_paths(ksa, torch_cuda, n, xres):
     """Every waterfall reduction path of the output stage: g = N/W of 1, 2, 4..256 (shuffles) and > 256 (LDS),
     on the single-workgroup and the four-step kernels."""
