@@ -389,6 +389,9 @@ def main():
                             "windows_per_unit": nwin, "sharding": sharding, "collective": collective}, **batch),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # counter traffic (L2 <-> fabric; Infinity-Cache hits included) per step over the stage's time
+                         "traffic_gbs": (traffic / avg_kernel_s / 1e9) if traffic else None,
+                         "traffic_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_unit": bpu,
                          # the whole step (spectrum stage + accumulate/stitch + collective) against the same bytes
