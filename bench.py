@@ -14,7 +14,9 @@ One "step" = one pass of the whole hot path over one HBM-resident batch per GPU:
 (zeroSpan: IQ -> window -> FFT -> |X| -> fold -> dB -> Cur/Max/Min/Avg + waterfall rows) or `--passes` whole scan
 passes (every tuned band's block -> spectrum -> clip/dB, then stitch + Max/Min/Avg + waterfall row per pass).
 With N > 1 every rank owns a contiguous time chunk (zeroSpan) or a contiguous range of tuned bands (scan) and ONE
-RCCL all-gather per step carries what the ranks must share (distributed.py); weak scaling (work per GPU fixed).
+RCCL all-gather per step carries what the ranks must share (distributed.py): the zeroSpan configs scale weakly (every
+GPU brings its own time chunk), the scan configs strongly (one fixed range split over the GPUs; halo exchange between
+neighbours + one all-gather of the partial waterfall rows).
 
 Launch: under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plainly as
 `python bench.py --gpus N`: the parent then starts N fresh rank processes itself (before it has touched the GPU),
@@ -161,7 +163,7 @@ def cpu_baseline_multicore(config_id, nwin, seconds=3.0, rounds=5, max_workers=1
         return None
     rates = sorted(sum(w[r][0] for w in per_worker) * nwin / max(w[r][1] for w in per_worker) for r in range(rounds))
     return {"value": rates[len(rates) // 2], "unit": "FFT/s", "cores": workers, "kind": "port",
-            "sample": "median of %d runs of >= %.1f s over %d processes (of %d usable cores; 16 = the box's CPU share), numpy float64"
+            "sample": "median of %d runs of >= %.1f s over %d processes (of %d usable cores; capped at 16 = the CPU share and process budget of a one-GPU box, a stated deviation from SURVEY 8d's 'all usable cores'), numpy float64"
                       % (rounds, seconds, workers, len(os.sched_getaffinity(0)))}
 
 
@@ -312,6 +314,9 @@ def main():
         sharding = "time-chunk"
         collective = ("RCCL: 1 all-gather of [4N + 128W] floats per rank per step over %d ranks, merged by ksa_merge_gathered_dev"
                       % world) if world > 1 else "none"
+        xb = (4 * n + 128 * eng.hm_width) * 4
+        coll_bytes = {"allgather_send": xb, "allgather_recv": xb * (world - 1)} if world > 1 else {}
+        scaling = "weak"                              # every GPU brings its own time chunk: work per GPU fixed
         batch = {"frames_per_gpu_per_step": frames}
     else:
         passes = args.passes or cfg["passes"]
@@ -326,8 +331,10 @@ def main():
         run = ksa_dist.ShardedScan(eng, rank, world)
         step = lambda: run.run_passes(iq, fmt, steps, passes)
         sharding = "freq-band"
-        collective = ("RCCL: 1 all-gather of the per-band spectra [passes][steps][N] per step over %d ranks, stitched on every rank"
+        collective = ("RCCL: halo send/recv of the overlap part of 1 band per pass to the right neighbour + 1 all-gather of the "
+                      "partial waterfall rows [min(passes,128)][W] per step over %d ranks; curves stay sharded by stitched range"
                       % world) if world > 1 else "none"
+        scaling = "strong"                            # the scan range is one fixed job split over the GPUs
         batch = {"passes_per_step": passes, "steps_per_pass": steps, "bands_on_rank0": mine, "total_entries": total}
 
     def fence():
@@ -339,6 +346,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if cfg["mode"] == "scan":
+        coll_bytes = run.collective_bytes() if world > 1 else {}
     eng.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -381,12 +390,13 @@ def main():
         traffic, traffic_src = pmc_traffic(key)
         out = {
             "metric": cfg["metric"], "value": ffts_per_s, "unit": "FFT/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "msamples_per_s": units_all * full / dt / 1e6,
             "config": dict({"workload": cfg["workload"], "baseline_config": args.config,
                             "input": "complex64" if args.fmt == "c64" else "uint8", "samples_per_unit": full,
-                            "windows_per_unit": nwin, "sharding": sharding, "collective": collective}, **batch),
+                            "windows_per_unit": nwin, "sharding": sharding, "collective": collective,
+                            "collective_bytes_per_rank_per_step": coll_bytes}, **batch),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          # counter traffic (L2 <-> fabric; Infinity-Cache hits included) per step over the stage's time

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define KSA_ABI_VERSION 1
+#define KSA_ABI_VERSION 2 /* 2: ksa_set_adj takes its target; allreduce_state, host-pointer scan pass, sharded scan entries */
 #define KSA_HM_ROWS 128 /* waterfall history depth: maxHM K:448, fftHMMax K:611 */
 
 /* d['curScanCumuMode'] K:31-34, K:58, consumed by data_cumu K:124-147 */
@@ -66,7 +66,8 @@ const char* ksa_last_error(void);
 /* Allocates tables, state and scratch on cfg->device.  Replaces the per-run setup of K:926-936. */
 int ksa_create(const ksa_config* cfg, ksa_engine** out);
 void ksa_destroy(ksa_engine* e);
-/* hip_stream: a hipStream_t (NULL = the device's default stream). */
+/* hip_stream: a hipStream_t (NULL = the device's default stream).  When the stream changes, work already
+ * enqueued on the old one is ordered in front of whatever is enqueued on the new one (event wait). */
 int ksa_set_stream(ksa_engine* e, void* hip_stream);
 int ksa_synchronize(ksa_engine* e);
 
@@ -112,10 +113,22 @@ int ksa_commit(ksa_engine* e, int64_t total_frames);
 int ksa_exchange_dev(ksa_engine* e, float** xchg_dev, int64_t* nfloats);
 int ksa_merge_gathered_dev(ksa_engine* e, const float* gathered_dev, int32_t world, int32_t frames_per_rank,
                            int32_t hm_index0);
+/* SURVEY 8(b) `allreduce_state(handles[], n)`: the same merge for n engines of ONE process (one per GPU of the
+ * node, or several on one GPU), no torch / RCCL needed -- the reference is a single process (K:1139-1155).  Engine r
+ * must hold the uncommitted batch of frames [r*frames_per_rank, (r+1)*frames_per_rank) of a run of n*frames_per_rank
+ * frames (ksa_set_hm_index((hm_index0 + r*frames_per_rank) % 128), then ksa_frames_dev(first_index = r*frames_per_rank,
+ * total_frames = n*frames_per_rank, commit = 0)).  Every engine receives every exchange block (4N + 128W floats:
+ * 320 KiB at fftSize 4096 -- latency, not bandwidth) by device-to-device / peer copies on its own stream, ordered
+ * behind the producers by events, and runs the merge kernel: afterwards all n engines hold the same Cur/Max/Min/Avg
+ * and waterfall ring, bit for bit (K:470-476, K:480-484 over the whole run).  Asynchronous like ksa_frames_dev. */
+int ksa_allreduce_state(ksa_engine* const* handles, int32_t n, int32_t frames_per_rank, int32_t hm_index0);
 /* GUI toggles bDataMax/bDataMin/bDataAvg (K:71-73, K:471-476) */
 int ksa_set_flags(ksa_engine* e, int32_t b_max, int32_t b_min, int32_t b_avg);
-/* d['Fft.Adj'] subtracted before the waterfall row (K:400-411, K:478-480); NULL clears. */
-int ksa_set_adj(ksa_engine* e, const float* adj_host, int32_t n);
+/* d['Fft.Adj'] subtracted before the waterfall row and in ksa_read_levels / ksa_read_highs (K:400-411, K:478-480,
+ * K:669, K:697).  scan = 0: the zeroSpan baseline, n == fft_size; scan != 0: the scan baseline, n ==
+ * scan_total_entries (a one-band scan has both lengths equal: the target is never guessed from n).
+ * adj_host == NULL clears that target. */
+int ksa_set_adj(ksa_engine* e, int32_t scan, const float* adj_host, int32_t n);
 int ksa_reset_state(ksa_engine* e);
 /* Any pointer may be NULL.  cur..avg: [fft_size]; hm: [KSA_HM_ROWS][hm_width]. */
 int ksa_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg, float* hm,
@@ -129,6 +142,11 @@ int ksa_set_hm_index(ksa_engine* e, int32_t hm_index);
  * 0 marks a band whose tune failed -> dummy ones (K:637-639). */
 int ksa_scan_pass_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride,
                       int32_t nsteps, const uint8_t* step_ok);
+/* The same pass from caller-owned HOST memory -- the body of the reference's step loop K:621-668 plus the row of
+ * K:696-697 with no device buffer on the caller's side: iq_host = [nsteps][full_size] samples (complex64 re,im or
+ * uint8 I,Q), staged through an engine-owned device buffer (nsteps <= max_frames).  Synchronises before returning. */
+int ksa_scan_pass_c64(ksa_engine* e, const float* iq_host, int32_t nsteps, const uint8_t* step_ok);
+int ksa_scan_pass_u8(ksa_engine* e, const uint8_t* iq_host, int32_t nsteps, const uint8_t* step_ok);
 /* Same, from per-step dB spectra already on the device ([nsteps][N], KSA_OUT_DB_CLIP units). */
 int ksa_scan_stitch_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps);
 /* A batch of `npasses` captured passes resident in HBM (block of pass p, step s at iq_dev + (p*nsteps + s)*
@@ -139,6 +157,31 @@ int ksa_scan_passes_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t 
                         int32_t nsteps, int32_t npasses, const uint8_t* step_ok);
 int ksa_scan_stitch_passes_dev(ksa_engine* e, const float* step_db_dev /* [npasses][nsteps][N] */,
                                int32_t nsteps, int32_t npasses);
+/* Band-sharded scan (SURVEY 8e "freq-band"): this engine owns the tuned bands [step_lo, step_hi) of every pass and
+ * the elements [elem_lo, elem_hi) of the stitched range (normally [step_lo*hop, step_hi*hop), the last rank up to
+ * totalEntries).  own_db_dev = [npasses][step_hi-step_lo][N] dB spectra of its bands; halo_db_dev =
+ * [npasses][nhalo][N] spectra of the nhalo bands in front of step_lo that still cover owned elements (the overlap
+ * K:645-650 averages: nhalo = ceil(N/hop) - 1 bands, 1 at the usual hop of N/2), received from the left neighbour.
+ * Runs exactly the updates of K:643-668 on the owned elements only, and writes this engine's PARTIAL waterfall rows
+ * (cell maxima over the owned elements, -inf where it owns none of a cell; K:696-697) for the batch's last
+ * min(npasses,128) passes to rows_dev [rows][scan_hm_width] (engine scratch, see ksa_scan_rows_dev). */
+int ksa_scan_stitch_range_dev(ksa_engine* e, const float* own_db_dev, const float* halo_db_dev, int32_t nhalo,
+                              int32_t step_lo, int32_t step_hi, int32_t nsteps, int32_t npasses,
+                              int32_t elem_lo, int32_t elem_hi);
+/* The partial rows of the last ksa_scan_stitch_range_dev: float[rows][scan_hm_width] on the device. */
+int ksa_scan_rows_dev(ksa_engine* e, float** rows_dev, int32_t* rows);
+/* gathered_dev = every rank's partial rows, [world][rows][scan_hm_width] in rank order: cell = NaN-propagating max
+ * over the ranks, stored into the ring rows of the batch's last `rows` passes; advances the ring by npasses. */
+int ksa_scan_merge_rows_dev(ksa_engine* e, const float* gathered_dev, int32_t world, int32_t rows, int32_t npasses);
+/* Single-process form of the whole exchange for n engines (one per GPU, or several on one): engine r has run the
+ * spectrum stage of its bands into own_db[r] ([npasses][hi_r-lo_r][N], device memory of engine r's GPU), bands split
+ * as [nsteps*r/n, nsteps*(r+1)/n).  Copies the halos between neighbours (peer copies), runs the range stitch on
+ * every engine, gathers and merges the partial waterfall rows.  Afterwards every engine holds its slice of
+ * Cur/Max/Min/Avg and the complete ring; ksa_scan_gather_state assembles the curves on the host. */
+int ksa_scan_allstitch(ksa_engine* const* handles, int32_t n, float* const* own_db_dev, int32_t nsteps, int32_t npasses);
+/* Host curves [scan_total_entries] assembled from the n engines' owned slices (any pointer may be NULL). */
+int ksa_scan_gather_state(ksa_engine* const* handles, int32_t n, int32_t nsteps, float* cur, float* max, float* min,
+                          float* avg);
 int ksa_scan_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg, float* hm,
                         int32_t* hm_index, int64_t* passes);
 int ksa_scan_state_dev(ksa_engine* e, float** state_dev, float** hm_ring_dev);
@@ -159,6 +202,10 @@ int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, fl
  * above +inf and the lowest point is never visited (K:258).  idx_host / lvl_host: [count]; *found = cells marked. */
 int ksa_read_highs(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, int32_t curve, double min_sep_cells,
                    int32_t count, int32_t* idx_host, float* lvl_host, int32_t* found);
+
+/* ---- pinned host memory for capture blocks (optional: any host pointer works, pinned ones copy faster) ------------ */
+int ksa_host_alloc(void** out, int64_t bytes);
+int ksa_host_free(void* p);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event timing of the spectrum kernel on the engine's stream: enable, run, then read the sum

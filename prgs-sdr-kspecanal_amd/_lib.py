@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # KSA_LIB: alternative build of the same ABI (kernel-variant experiments); default = the in-tree library
 LIB_PATH = os.environ.get("KSA_LIB") or os.path.join(HERE, "libksa.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 HM_ROWS = 128
 CUMU = {"RAW": 0, "AVG": 1, "MAX": 2, "MIN": 3}
 FMT_C64, FMT_U8 = 0, 1
@@ -54,21 +54,31 @@ SIGNATURES = {
     "ksa_exchange_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     "ksa_merge_gathered_dev": (C.c_int, [_P, _P, _I32, _I32, _I32]),
     "ksa_set_flags": (C.c_int, [_P, _I32, _I32, _I32]),
-    "ksa_set_adj": (C.c_int, [_P, _P, _I32]),
+    "ksa_allreduce_state": (C.c_int, [C.POINTER(_P), _I32, _I32, _I32]),
+    "ksa_set_adj": (C.c_int, [_P, _I32, _P, _I32]),
     "ksa_reset_state": (C.c_int, [_P]),
     "ksa_read_state": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(_I32), C.POINTER(_I64)]),
     "ksa_state_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "ksa_set_hm_index": (C.c_int, [_P, _I32]),
     "ksa_scan_pass_dev": (C.c_int, [_P, _P, _I32, _I64, _I32, _P]),
+    "ksa_scan_pass_c64": (C.c_int, [_P, _P, _I32, _P]),
+    "ksa_scan_pass_u8": (C.c_int, [_P, _P, _I32, _P]),
     "ksa_scan_stitch_dev": (C.c_int, [_P, _P, _I32]),
     "ksa_scan_passes_dev": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "ksa_scan_stitch_passes_dev": (C.c_int, [_P, _P, _I32, _I32]),
+    "ksa_scan_stitch_range_dev": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "ksa_scan_rows_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I32)]),
+    "ksa_scan_merge_rows_dev": (C.c_int, [_P, _P, _I32, _I32, _I32]),
+    "ksa_scan_allstitch": (C.c_int, [C.POINTER(_P), _I32, C.POINTER(_P), _I32, _I32]),
+    "ksa_scan_gather_state": (C.c_int, [C.POINTER(_P), _I32, _I32, _P, _P, _P, _P]),
     "ksa_scan_read_state": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(_I32), C.POINTER(_I64)]),
     "ksa_scan_state_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "ksa_scan_reset": (C.c_int, [_P]),
     "ksa_scan_set_base_is_raw": (C.c_int, [_P, _I32]),
     "ksa_read_levels": (C.c_int, [_P, _I32, _I32, _I32, _P]),
     "ksa_read_highs": (C.c_int, [_P, _I32, _I32, _I32, _I32, C.c_double, _I32, _P, _P, C.POINTER(_I32)]),
+    "ksa_host_alloc": (C.c_int, [C.POINTER(_P), _I64]),
+    "ksa_host_free": (C.c_int, [_P]),
     "ksa_prof_enable": (C.c_int, [_P, _I32]),
     "ksa_prof_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "ksa_kernel_info": (C.c_int, [_P] + [C.POINTER(_I32)] * 5),
@@ -100,12 +110,14 @@ def load(path=LIB_PATH):
         raise KsaError("libksa.so is missing at %s -- build it with `python __graft_entry__.py` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
     lib = C.CDLL(path)
+    lib.ksa_abi_version.restype = C.c_int
+    if lib.ksa_abi_version() != ABI_VERSION:      # checked first: a stale build is named as such, not as a missing symbol
+        raise KsaError("%s has ABI %d, this binding expects %d -- rebuild it (python __graft_entry__.py)"
+                       % (path, lib.ksa_abi_version(), ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.ksa_abi_version() != ABI_VERSION:
-        raise KsaError("libksa.so ABI %d, binding expects %d" % (lib.ksa_abi_version(), ABI_VERSION))
     return lib
 
 

@@ -92,6 +92,18 @@ struct ksa_engine {
   int* d_highs = nullptr;         // peak markers: [HIGHS_MAX] cell | [HIGHS_MAX] level (float bits) | found
   float* d_parts = nullptr;       // [capacity][N] partial folds of the window-split (latency) mode
   int levels_cap = 0;
+  // multi-engine merges inside one process (ksa_allreduce_state, ksa_scan_allstitch) and the host-pointer scan pass
+  float* d_gather = nullptr;      // [n][4N + 128W] every engine's exchange block, or [n][rows][scan_hm_width]
+  size_t gather_cap = 0;          // floats
+  void* d_scan_stage = nullptr;   // [nsteps][full_size] capture blocks of ksa_scan_pass_c64 / _u8
+  size_t scan_stage_cap = 0;      // bytes
+  float* d_scan_rows = nullptr;   // [128][scan_hm_width] partial waterfall rows of a band-sharded batch
+  int scan_rows = 0;              // rows the last ksa_scan_stitch_range_dev wrote
+  int scan_rows_passes = 0;       // ... and the passes of that batch (ring advance of ksa_scan_merge_rows_dev)
+  float* d_scan_halo = nullptr;   // [nhalo][npasses][N] halo bands (ksa_scan_allstitch)
+  float* d_scan_send = nullptr;   // [nhalo][npasses][N] own bands packed for the right neighbours
+  size_t scan_halo_cap = 0, scan_send_cap = 0;   // floats
+  hipEvent_t ev_ready = nullptr, ev_copied = nullptr, ev_stream = nullptr;
   ksa::FourStep four;           // N > 262144: four-step path (column / row kernels)
   // 16384 < N <= 262144: radix-16 decimation in frequency in front of the single-workgroup kernel (ksa_dif16.hpp)
   int sub_n = 0;                // size of the single-workgroup transform: fft_size (path 0) or fft_size/16 (path 2)
@@ -172,8 +184,14 @@ int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
   // large batches of 1024 .. 4096-point transforms: two frames per workgroup in packed fp32
   if constexpr (ksa::Plan<N>::S == 1 && ksa::Plan<N>::T <= 256 && ksa::Plan<N>::M >= 2) {
     if (e->pair_ok) {
-      if (configure_only) { if (launch_pair<N, FMT, RM>(e, p, true)) return 1; }
-      else if (p.nframes >= 2 * e->num_cu * e->pair_bpc) return launch_pair<N, FMT, RM>(e, p, false);
+      if (configure_only) {
+        // every reuse variant a later batch can pick (RAW mode runs RM = 0 whatever the hops); the one in use last,
+        // so that pair_bpc / pair_vgprs describe it
+        if (RM != 0 && launch_pair<N, FMT, 0>(e, p, true)) return 1;
+        if (RM != 4 && launch_pair<N, FMT, 4>(e, p, true)) return 1;
+        if (RM != 8 && launch_pair<N, FMT, 8>(e, p, true)) return 1;
+        if (launch_pair<N, FMT, RM>(e, p, true)) return 1;
+      } else if (p.nframes >= 2 * e->num_cu * e->pair_bpc) return launch_pair<N, FMT, RM>(e, p, false);
     }
   }
   // fold mode as a template constant (Tune<N>::fold_const) or as a run-time branch inside the window loop
@@ -537,6 +555,19 @@ int scan_reset(ksa_engine* e) {
 
 size_t sample_bytes(int fmt) { return fmt == KSA_FMT_C64 ? 8 : 2; }
 
+// Grow-only device scratch of an engine (on its device, which the caller has made current).
+template <typename T>
+int ensure(T** ptr, size_t* cap, size_t count) {
+  if (*ptr && *cap >= count) return 0;
+  if (*ptr) hipFree(*ptr);
+  *ptr = nullptr;
+  *cap = 0;
+  HIP_OK(hipMalloc(reinterpret_cast<void**>(ptr), std::max<size_t>(count, 1) * sizeof(T)));
+  *cap = count;
+  return 0;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -600,7 +631,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     // Two frames per workgroup in packed fp32 (ksa_kernels_pair.hpp).  Measured against the one-frame kernel on MI355X
     // (tools/pair_sweep.sh, hops 0.5 / 0.25 / 0.1): N = 1024 +14..+30 %, N = 2048 -3..-5 %, N = 4096 0..-5 % -- on by
     // default for 1024 only.  KSA_PAIR_ALL enables it for 1024 .. 4096, KSA_NO_PAIR disables it (A/B switches).
-    e->pair_ok = !getenv("KSA_NO_PAIR") && (sn == 1024 || (getenv("KSA_PAIR_ALL") && sn >= 1024 && sn <= 4096));
+    e->pair_ok = e->path == 0 && !getenv("KSA_NO_PAIR") && (sn == 1024 || (getenv("KSA_PAIR_ALL") && sn >= 1024 && sn <= 4096));
     if (e->plan32) {
       // folded twiddles of dft16_fused for a base twiddle of `beta` turns: w^4, w^8, w^12, then w^n2 * W16^(n2*k1)
       auto fused15 = [](double beta, int e) {
@@ -688,9 +719,15 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
       if ((rc = upload(&e->d_starts_b, sb.data(), sb.size()))) return bail(rc);
       // scratch: Z = 8 N bytes per window.  Chunks of <= KSA_FS_SCRATCH_MB (default below) of Z
       const size_t per_frame = (size_t)nw * n * sizeof(float2);
+      // 32-bit offsets inside the kernels: a pseudo frame is nwin*N1 complex points addressed in bytes
+      if ((long long)nw * n1 >= (1ll << 28)) return bail(fail("num_windows %d x fft_size/16 %d exceeds 2^28 points per frame", nw, n1));
       size_t budget = (size_t)KSA_DIF_SCRATCH_MB_DEFAULT << 20;
-      if (const char* mb = getenv("KSA_FS_SCRATCH_MB")) budget = (size_t)atol(mb) << 20;   // A/B switch for measurements
+      if (const char* mb = getenv("KSA_FS_SCRATCH_MB")) {        // A/B switch for measurements; nonsense keeps the default
+        const long v = atol(mb);
+        if (v >= 1 && v <= (256l << 10)) budget = (size_t)v << 20;
+      }
       e->dif_chunk = (int)std::min<size_t>(std::max<size_t>(1, budget / per_frame), (size_t)cfg->max_frames);
+      e->dif_chunk = std::min(e->dif_chunk, 4095);               // gridDim.z of dif16_kernel, 16*chunk pseudo frames
       hipError_t he2;
       if ((he2 = hipMalloc(reinterpret_cast<void**>(&e->d_dif_z), per_frame * e->dif_chunk)) != hipSuccess)
         return bail(fail("hipMalloc(%zu) for the first-stage scratch: %s", per_frame * e->dif_chunk, hipGetErrorString(he2)));
@@ -737,7 +774,9 @@ void ksa_destroy(ksa_engine* e) {
   hipSetDevice(e->cfg.device);
   hipDeviceSynchronize();
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-  void* ptrs[] = {e->d_starts, e->d_start_last, e->d_window, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
+  for (hipEvent_t ev : {e->ev_ready, e->ev_copied, e->ev_stream}) if (ev) hipEventDestroy(ev);
+  void* ptrs[] = {e->d_gather, e->d_scan_stage, e->d_scan_rows, e->d_scan_halo, e->d_scan_send,
+                  e->d_starts, e->d_start_last, e->d_window, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
                   e->d_iq_stage, e->d_frames, e->d_part, e->d_xchg, e->d_state, e->d_scan_state, e->d_scan_hm,
                   e->d_levels, e->d_parts, e->d_highs, e->d_scan_avg_rows, e->d_dif_tw, e->d_dif_z, e->d_dif_y, e->d_ones, e->d_starts_b};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -747,7 +786,14 @@ void ksa_destroy(ksa_engine* e) {
 
 int ksa_set_stream(ksa_engine* e, void* hip_stream) {
   if (!e) return fail("null engine");
-  e->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  hipStream_t ns = reinterpret_cast<hipStream_t>(hip_stream);
+  if (ns == e->stream) return 0;
+  // engine-owned buffers (state, scratch, rings) may still be in use on the old stream: order the new one behind it
+  HIP_OK(hipSetDevice(e->cfg.device));
+  if (!e->ev_stream) HIP_OK(hipEventCreateWithFlags(&e->ev_stream, hipEventDisableTiming));
+  HIP_OK(hipEventRecord(e->ev_stream, e->stream));
+  HIP_OK(hipStreamWaitEvent(ns, e->ev_stream, 0));
+  e->stream = ns;
   return 0;
 }
 
@@ -878,22 +924,17 @@ int ksa_set_flags(ksa_engine* e, int32_t b_max, int32_t b_min, int32_t b_avg) {
   return 0;
 }
 
-int ksa_set_adj(ksa_engine* e, const float* adj_host, int32_t n) {
+int ksa_set_adj(ksa_engine* e, int32_t scan, const float* adj_host, int32_t n) {
   if (!e) return fail("null engine");
+  if (scan && !e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
   HIP_OK(hipSetDevice(e->cfg.device));
   HIP_OK(hipStreamSynchronize(e->stream));
-  if (!adj_host) {
-    if (e->d_adj) hipFree(e->d_adj);
-    if (e->d_scan_adj) hipFree(e->d_scan_adj);
-    e->d_adj = e->d_scan_adj = nullptr;
-    return 0;
-  }
-  float** slot = nullptr;
-  if (n == e->cfg.fft_size) slot = &e->d_adj;
-  else if (e->cfg.scan_total_entries && n == e->cfg.scan_total_entries) slot = &e->d_scan_adj;
-  else return fail("adj length %d matches neither fft_size nor scan_total_entries", n);
+  float** slot = scan ? &e->d_scan_adj : &e->d_adj;
   if (*slot) hipFree(*slot);
   *slot = nullptr;
+  if (!adj_host) return 0;
+  const int want = scan ? e->cfg.scan_total_entries : e->cfg.fft_size;
+  if (n != want) return fail("adj length %d, the %s baseline needs %d", n, scan ? "scan" : "zeroSpan", want);
   return upload(slot, adj_host, (size_t)n);
 }
 
@@ -941,18 +982,31 @@ int ksa_set_hm_index(ksa_engine* e, int32_t hm_index) {
   return 0;
 }
 
-static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int npasses) {
+// Stitch + Max/Min/Avg over the elements [elem_lo, elem_hi) from the bands [step_lo, step_hi) (+ nhalo halo bands in
+// front of them).  ranged == false: the whole range on one engine, the waterfall rows go straight into the ring;
+// ranged == true: partial rows into d_scan_rows for ksa_scan_merge_rows_dev.
+static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int npasses, bool ranged = false,
+                       const float* halo_db_dev = nullptr, int nhalo = 0, int step_lo = 0, int step_hi = -1,
+                       int elem_lo = 0, int elem_hi = -1) {
   if (!e || !step_db_dev) return fail("null argument");
   const ksa_config& c = e->cfg;
   if (!c.scan_total_entries) return fail("engine was created without scan geometry");
   if (nsteps < 1 || npasses < 1) return fail("nsteps and npasses must be >= 1");
+  if (step_hi < 0) step_hi = nsteps;
+  if (elem_hi < 0) elem_hi = c.scan_total_entries;
   HIP_OK(hipSetDevice(c.device));
   ksa::StitchParams s{};
   s.step_db = step_db_dev;
+  s.halo_db = halo_db_dev;
   s.n = c.fft_size;
   s.nsteps = nsteps;
   s.hop = c.scan_hop;
   s.total = c.scan_total_entries;
+  s.step_lo = step_lo;
+  s.own_steps = step_hi - step_lo;
+  s.nhalo = nhalo;
+  s.e_lo = elem_lo;
+  s.e_hi = elem_hi;
   s.state = e->d_scan_state;
   s.first_pass = e->scan_passes == 0;
   s.b_max = e->b_max;
@@ -960,7 +1014,7 @@ static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int 
   s.base_is_raw = e->scan_base_is_raw;
   s.npasses = npasses;
   const int rows = std::min(npasses, KSA_HM_ROWS);       // only the last 128 passes of a batch reach the ring
-  if (npasses > 1) {
+  if (npasses > 1 || ranged) {
     // Fft.Avg after each of those passes: the waterfall row of a pass is built from it (K:696-697)
     if (!e->d_scan_avg_rows)
       HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_scan_avg_rows), (size_t)KSA_HM_ROWS * s.total * 4));
@@ -968,8 +1022,19 @@ static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int 
     s.avg_row0 = npasses - rows;
   }
   const int tb = 256;
-  hipLaunchKernelGGL(ksa::scan_stitch_kernel, dim3((s.total + tb - 1) / tb), dim3(tb), 0, e->stream, s);
+  const int elems = elem_hi - elem_lo;
+  if (elems > 0) hipLaunchKernelGGL(ksa::scan_stitch_kernel, dim3((elems + tb - 1) / tb), dim3(tb), 0, e->stream, s);
   const int g = c.scan_total_entries / c.scan_hm_width;
+  if (ranged) {
+    if (!e->d_scan_rows) HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_scan_rows), (size_t)KSA_HM_ROWS * c.scan_hm_width * 4));
+    hipLaunchKernelGGL(ksa::rowmax_rows_range_kernel, dim3(c.scan_hm_width, rows), dim3(64), 0, e->stream,
+                       e->d_scan_avg_rows, e->d_scan_adj, c.scan_hm_width, g, elem_lo, elem_hi, e->d_scan_rows);
+    HIP_OK(hipGetLastError());
+    e->scan_rows = rows;
+    e->scan_rows_passes = npasses;
+    e->scan_passes += npasses;       // (the ring advances in ksa_scan_merge_rows_dev)
+    return 0;
+  }
   if (npasses == 1) {
     hipLaunchKernelGGL(ksa::rowmax_kernel, dim3((c.scan_hm_width + tb - 1) / tb), dim3(tb), 0, e->stream,
                        e->d_scan_state + (size_t)3 * s.total, e->d_scan_adj, c.scan_hm_width, g,
@@ -982,6 +1047,236 @@ static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int 
   HIP_OK(hipGetLastError());
   e->scan_passes += npasses;
   e->scan_hm_index = (e->scan_hm_index + npasses) % KSA_HM_ROWS;  // K:732, once per pass
+  return 0;
+}
+
+// Bands in front of step_lo that still cover elements from step_lo*hop on: ceil(N/hop) - 1, at most step_lo.
+static int halo_bands(const ksa_config& c, int step_lo) { return std::min(step_lo, (c.fft_size + c.scan_hop - 1) / c.scan_hop - 1); }
+
+int ksa_scan_stitch_range_dev(ksa_engine* e, const float* own_db_dev, const float* halo_db_dev, int32_t nhalo,
+                              int32_t step_lo, int32_t step_hi, int32_t nsteps, int32_t npasses, int32_t elem_lo,
+                              int32_t elem_hi) {
+  if (!e) return fail("null engine");
+  const ksa_config& c = e->cfg;
+  if (!c.scan_total_entries) return fail("engine was created without scan geometry");
+  if (nsteps < 1 || npasses < 1) return fail("nsteps and npasses must be >= 1");
+  if (step_lo < 0 || step_hi < step_lo || step_hi > nsteps) return fail("bands [%d,%d) outside the pass of %d", step_lo, step_hi, nsteps);
+  if (elem_lo < 0 || elem_hi < elem_lo || elem_hi > c.scan_total_entries)
+    return fail("elements [%d,%d) outside the stitched range of %d", elem_lo, elem_hi, c.scan_total_entries);
+  if (nhalo < 0 || nhalo > step_lo) return fail("nhalo %d outside 0..step_lo(%d)", nhalo, step_lo);
+  if (elem_hi > elem_lo) {
+    // every band that covers an owned element must be at hand: i0(elem_lo) >= step_lo - nhalo, i1(elem_hi-1) < step_hi
+    const int n = c.fft_size, hop = c.scan_hop;
+    const int i0 = elem_lo - n + 1 <= 0 ? 0 : (elem_lo - n + hop) / hop;
+    const int i1 = std::min((elem_hi - 1) / hop, nsteps - 1);
+    if (i0 <= i1 && (i0 < step_lo - nhalo || i1 >= step_hi))
+      return fail("elements [%d,%d) are covered by bands %d..%d, at hand are %d..%d", elem_lo, elem_hi, i0, i1, step_lo - nhalo, step_hi - 1);
+    if (step_hi > step_lo && !own_db_dev) return fail("null own_db_dev");
+    if (nhalo > 0 && !halo_db_dev) return fail("null halo_db_dev");
+  }
+  const float* own = own_db_dev ? own_db_dev : e->d_scan_state;   // (an engine that owns no band reads nothing)
+  return scan_stitch(e, own, nsteps, npasses, true, halo_db_dev, nhalo, step_lo, step_hi, elem_lo, elem_hi);
+}
+
+int ksa_scan_rows_dev(ksa_engine* e, float** rows_dev, int32_t* rows) {
+  if (!e || !rows_dev || !rows) return fail("null argument");
+  if (!e->d_scan_rows || e->scan_rows <= 0) return fail("no band-sharded batch pending (ksa_scan_stitch_range_dev first)");
+  *rows_dev = e->d_scan_rows;
+  *rows = e->scan_rows;
+  return 0;
+}
+
+int ksa_scan_merge_rows_dev(ksa_engine* e, const float* gathered_dev, int32_t world, int32_t rows, int32_t npasses) {
+  if (!e || !gathered_dev) return fail("null argument");
+  const ksa_config& c = e->cfg;
+  if (!c.scan_total_entries) return fail("engine was created without scan geometry");
+  if (world < 1) return fail("world %d < 1", world);
+  if (rows != e->scan_rows || npasses != e->scan_rows_passes)
+    return fail("ksa_scan_merge_rows_dev: %d rows of %d passes pending, call says %d of %d", e->scan_rows, e->scan_rows_passes, rows, npasses);
+  HIP_OK(hipSetDevice(c.device));
+  const int cells = rows * c.scan_hm_width;
+  hipLaunchKernelGGL(ksa::scan_merge_rows_kernel, dim3((cells + 255) / 256), dim3(256), 0, e->stream, gathered_dev, world,
+                     rows, c.scan_hm_width, e->d_scan_hm, (e->scan_hm_index + npasses - rows) % KSA_HM_ROWS);
+  HIP_OK(hipGetLastError());
+  e->scan_hm_index = (e->scan_hm_index + npasses) % KSA_HM_ROWS;
+  e->scan_rows = e->scan_rows_passes = 0;
+  return 0;
+}
+
+// device-to-device copy issued on `s` (a stream of dst_dev): peer copy when the devices differ
+static int copy_d2d(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t s) {
+  if (!bytes) return 0;
+  if (dst_dev == src_dev) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+  else HIP_OK(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s));
+  return 0;
+}
+
+static int ensure_events(ksa_engine* e) {
+  if (!e->ev_ready) HIP_OK(hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming));
+  if (!e->ev_copied) HIP_OK(hipEventCreateWithFlags(&e->ev_copied, hipEventDisableTiming));
+  return 0;
+}
+
+// every engine -> every engine: engine i's stream receives block_of(j) of all j into its d_gather[j], behind the
+// producers (ev_ready) ; ev_copied_i marks the end of i's copies so that no producer overwrites a block too early
+static int gather_all(ksa_engine* const* h, int n, size_t nfloats, float* (*block_of)(ksa_engine*)) {
+  for (int j = 0; j < n; ++j) {
+    HIP_OK(hipSetDevice(h[j]->cfg.device));
+    if (ensure_events(h[j])) return 1;
+    HIP_OK(hipEventRecord(h[j]->ev_ready, h[j]->stream));
+  }
+  for (int i = 0; i < n; ++i) {
+    ksa_engine* e = h[i];
+    HIP_OK(hipSetDevice(e->cfg.device));
+    if (ensure(&e->d_gather, &e->gather_cap, (size_t)n * nfloats)) return 1;
+    for (int j = 0; j < n; ++j) {
+      if (j != i) HIP_OK(hipStreamWaitEvent(e->stream, h[j]->ev_ready, 0));
+      if (copy_d2d(e->d_gather + (size_t)j * nfloats, e->cfg.device, block_of(h[j]), h[j]->cfg.device, nfloats * 4, e->stream)) return 1;
+    }
+    HIP_OK(hipEventRecord(e->ev_copied, e->stream));
+  }
+  for (int i = 0; i < n; ++i) {
+    HIP_OK(hipSetDevice(h[i]->cfg.device));
+    for (int j = 0; j < n; ++j)
+      if (j != i) HIP_OK(hipStreamWaitEvent(h[i]->stream, h[j]->ev_copied, 0));
+  }
+  return 0;
+}
+
+static int check_handles(ksa_engine* const* h, int n) {
+  if (!h || n < 1) return fail("need at least one engine handle");
+  for (int i = 0; i < n; ++i) {
+    if (!h[i]) return fail("engine handle %d is null", i);
+    for (int j = 0; j < i; ++j) if (h[j] == h[i]) return fail("engine handle %d is handle %d again", i, j);
+    const ksa_config &a = h[0]->cfg, &b = h[i]->cfg;
+    if (a.fft_size != b.fft_size || a.hm_width != b.hm_width || a.scan_total_entries != b.scan_total_entries ||
+        a.scan_hop != b.scan_hop || a.scan_hm_width != b.scan_hm_width)
+      return fail("engine %d has a different geometry than engine 0", i);
+  }
+  return 0;
+}
+
+int ksa_allreduce_state(ksa_engine* const* handles, int32_t n, int32_t frames_per_rank, int32_t hm_index0) {
+  if (check_handles(handles, n)) return 1;
+  if (frames_per_rank < 1) return fail("frames_per_rank %d < 1", frames_per_rank);
+  if (hm_index0 < 0 || hm_index0 >= KSA_HM_ROWS) return fail("hm_index0 %d outside 0..127", hm_index0);
+  for (int i = 0; i < n; ++i)
+    if (handles[i]->pending_frames != frames_per_rank)
+      return fail("engine %d has %d frames pending, frames_per_rank says %d", i, handles[i]->pending_frames, frames_per_rank);
+  const size_t nfloats = 4 * (size_t)handles[0]->cfg.fft_size + (size_t)KSA_HM_ROWS * handles[0]->cfg.hm_width;
+  if (gather_all(handles, n, nfloats, +[](ksa_engine* e) { return e->d_xchg; })) return 1;
+  for (int i = 0; i < n; ++i)
+    if (ksa_merge_gathered_dev(handles[i], handles[i]->d_gather, n, frames_per_rank, hm_index0)) return 1;
+  return 0;
+}
+
+int ksa_scan_allstitch(ksa_engine* const* handles, int32_t n, float* const* own_db_dev, int32_t nsteps, int32_t npasses) {
+  if (check_handles(handles, n)) return 1;
+  if (!own_db_dev) return fail("null own_db_dev");
+  const ksa_config& c = handles[0]->cfg;
+  if (!c.scan_total_entries) return fail("engines were created without scan geometry");
+  if (nsteps < 1 || npasses < 1) return fail("nsteps and npasses must be >= 1");
+  const size_t band = (size_t)npasses * c.fft_size;   // floats of one band over the batch
+  auto lo_of = [&](int r) { return (int)((long long)nsteps * r / n); };
+  // 1. every engine packs the bands its right neighbours need ([band][npasses][N]) behind its spectrum stage
+  for (int r = 0; r < n; ++r) {
+    ksa_engine* e = handles[r];
+    const int lo = lo_of(r), hi = lo_of(r + 1), mine = hi - lo;
+    HIP_OK(hipSetDevice(e->cfg.device));
+    if (ensure_events(e)) return 1;
+    const int keep = std::min(mine, (c.fft_size + c.scan_hop - 1) / c.scan_hop - 1);   // its last bands may be someone's halo
+    if (keep > 0 && r + 1 < n) {
+      if (!own_db_dev[r]) return fail("own_db_dev[%d] is null", r);
+      if (ensure(&e->d_scan_send, &e->scan_send_cap, (size_t)keep * band)) return 1;
+      for (int b = 0; b < keep; ++b)     // band hi-keep+b of every pass -> send[b][pass][N]
+        HIP_OK(hipMemcpy2DAsync(e->d_scan_send + (size_t)b * band, (size_t)c.fft_size * 4,
+                                own_db_dev[r] + (size_t)(mine - keep + b) * c.fft_size, (size_t)mine * c.fft_size * 4,
+                                (size_t)c.fft_size * 4, (size_t)npasses, hipMemcpyDeviceToDevice, e->stream));
+    }
+    HIP_OK(hipEventRecord(e->ev_ready, e->stream));
+  }
+  // 2. halos: band j of rank r's halo comes from the rank that owns j
+  for (int r = 0; r < n; ++r) {
+    ksa_engine* e = handles[r];
+    const int lo = lo_of(r), hi = lo_of(r + 1);
+    const int nhalo = halo_bands(c, lo);
+    HIP_OK(hipSetDevice(e->cfg.device));
+    if (nhalo > 0 && ensure(&e->d_scan_halo, &e->scan_halo_cap, (size_t)nhalo * band)) return 1;
+    for (int j = lo - nhalo; j < lo; ++j) {
+      int src = r - 1;
+      while (src > 0 && lo_of(src) > j) --src;
+      ksa_engine* s = handles[src];
+      const int shi = lo_of(src + 1), smine = shi - lo_of(src);
+      const int skeep = std::min(smine, (c.fft_size + c.scan_hop - 1) / c.scan_hop - 1);
+      const int b = j - (shi - skeep);                 // position of band j in src's send block
+      if (b < 0) return fail("internal: band %d is not in rank %d's send block", j, src);
+      HIP_OK(hipStreamWaitEvent(e->stream, s->ev_ready, 0));
+      if (copy_d2d(e->d_scan_halo + (size_t)(j - (lo - nhalo)) * band, e->cfg.device, s->d_scan_send + (size_t)b * band,
+                   s->cfg.device, band * 4, e->stream)) return 1;
+    }
+    const int elem_lo = lo * c.scan_hop, elem_hi = r == n - 1 ? c.scan_total_entries : std::min(c.scan_total_entries, hi * c.scan_hop);
+    if (ksa_scan_stitch_range_dev(e, own_db_dev[r], e->d_scan_halo, nhalo, lo, hi, nsteps, npasses, std::min(elem_lo, elem_hi), elem_hi)) return 1;
+  }
+  // 3. partial waterfall rows: all-to-all copies, merged on every engine
+  const int rows = std::min(npasses, KSA_HM_ROWS);
+  const size_t nfloats = (size_t)rows * c.scan_hm_width;
+  if (gather_all(handles, n, nfloats, +[](ksa_engine* e) { return e->d_scan_rows; })) return 1;
+  for (int i = 0; i < n; ++i)
+    if (ksa_scan_merge_rows_dev(handles[i], handles[i]->d_gather, n, rows, npasses)) return 1;
+  return 0;
+}
+
+int ksa_scan_gather_state(ksa_engine* const* handles, int32_t n, int32_t nsteps, float* cur, float* max, float* min, float* avg) {
+  if (check_handles(handles, n)) return 1;
+  const ksa_config& c = handles[0]->cfg;
+  if (!c.scan_total_entries) return fail("engines were created without scan geometry");
+  if (nsteps < 1) return fail("nsteps must be >= 1");
+  float* dst[4] = {cur, max, min, avg};
+  const size_t t = (size_t)c.scan_total_entries;
+  for (int r = 0; r < n; ++r) {
+    ksa_engine* e = handles[r];
+    const long long lo = (long long)nsteps * r / n, hi = (long long)nsteps * (r + 1) / n;
+    const size_t e_lo = std::min<size_t>(t, (size_t)lo * c.scan_hop), e_hi = r == n - 1 ? t : std::min<size_t>(t, (size_t)hi * c.scan_hop);
+    HIP_OK(hipSetDevice(e->cfg.device));
+    for (int k = 0; k < 4; ++k)
+      if (dst[k] && e_hi > e_lo)
+        HIP_OK(hipMemcpyAsync(dst[k] + e_lo, e->d_scan_state + k * t + e_lo, (e_hi - e_lo) * 4, hipMemcpyDeviceToHost, e->stream));
+  }
+  for (int r = 0; r < n; ++r) {
+    HIP_OK(hipSetDevice(handles[r]->cfg.device));
+    HIP_OK(hipStreamSynchronize(handles[r]->stream));
+  }
+  return 0;
+}
+
+static int scan_pass_host(ksa_engine* e, const void* iq_host, int fmt, int nsteps, const uint8_t* step_ok) {
+  if (!e || !iq_host) return fail("null argument");
+  if (!e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
+  if (nsteps < 1 || nsteps > e->cfg.max_frames) return fail("nsteps %d outside 1..max_frames(%d)", nsteps, e->cfg.max_frames);
+  HIP_OK(hipSetDevice(e->cfg.device));
+  const size_t bytes = (size_t)nsteps * e->cfg.full_size * sample_bytes(fmt);
+  if (ensure(reinterpret_cast<unsigned char**>(&e->d_scan_stage), &e->scan_stage_cap, bytes)) return 1;
+  HIP_OK(hipMemcpyAsync(e->d_scan_stage, iq_host, bytes, hipMemcpyHostToDevice, e->stream));
+  if (ksa_scan_passes_dev(e, e->d_scan_stage, fmt, e->cfg.full_size, nsteps, 1, step_ok)) return 1;
+  HIP_OK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int ksa_scan_pass_c64(ksa_engine* e, const float* iq_host, int32_t nsteps, const uint8_t* step_ok) {
+  return scan_pass_host(e, iq_host, KSA_FMT_C64, nsteps, step_ok);
+}
+int ksa_scan_pass_u8(ksa_engine* e, const uint8_t* iq_host, int32_t nsteps, const uint8_t* step_ok) {
+  return scan_pass_host(e, iq_host, KSA_FMT_U8, nsteps, step_ok);
+}
+
+int ksa_host_alloc(void** out, int64_t bytes) {
+  if (!out || bytes < 1) return fail("ksa_host_alloc: null pointer or size < 1");
+  *out = nullptr;
+  HIP_OK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  return 0;
+}
+int ksa_host_free(void* p) {
+  if (p) HIP_OK(hipHostFree(p));
   return 0;
 }
 

@@ -689,8 +689,11 @@ __global__ void commit_kernel(const float* partial, float* state, int n, int has
 // The reference copies the first covering step (RAW, K:644) and halves-in every later one (AVG,
 // K:649); after the last covering step the value is final and is what Max/Min/Avg see (K:657-668).
 struct StitchParams {
-  const float* step_db;  // [npasses][nsteps][N]
+  const float* step_db;  // [npasses][own_steps][N]: the bands [step_lo, step_lo + own_steps) of every pass
+  const float* halo_db;  // [nhalo][npasses][N] (band major): bands [step_lo - nhalo, step_lo), or null
   int n, nsteps, hop, total;
+  int step_lo, own_steps, nhalo;   // single engine: 0, nsteps, 0
+  int e_lo, e_hi;                  // elements of the stitched range this launch owns (single engine: 0, total)
   float* state;          // [4][total] : cur, max, min, avg
   int first_pass;        // the first pass of this call is pass 0 of the run: it seeds Avg by copy (K:615-618)
   int b_max, b_min;
@@ -702,9 +705,11 @@ struct StitchParams {
 
 // One thread = one element of the stitched range, walking the passes of the batch in order: exactly the
 // sequence of updates the reference applies pass after pass, with the state in registers in between.
+// A band-sharded scan launches it over the elements one engine owns; bands in front of its own ones that still
+// cover those elements come from the halo block its left neighbours sent.
 __global__ __launch_bounds__(256) void scan_stitch_kernel(const StitchParams p) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= p.total) return;
+  const int e = p.e_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.e_hi) return;
   int i0 = (e - p.n + p.hop) / p.hop;  // ceil((e-n+1)/hop) for e-n+1 > 0
   if (e - p.n + 1 <= 0) i0 = 0;
   int i1 = e / p.hop;
@@ -712,18 +717,36 @@ __global__ __launch_bounds__(256) void scan_stitch_kernel(const StitchParams p) 
   const bool covered = i0 <= i1;       // not covered: the state keeps its value
   const int tot = p.total;
   float cur = p.state[e], mx = p.state[tot + e], mn = p.state[2 * tot + e], av = p.state[3 * tot + e];
+  // spectrum of band i in pass 0 and the distance between passes (own block or halo block)
+  auto band = [&](int i, long long& pass_stride) -> const float* {
+    if (i >= p.step_lo) {
+      pass_stride = (long long)p.own_steps * p.n;
+      return p.step_db + (long long)(i - p.step_lo) * p.n;
+    }
+    pass_stride = p.n;
+    return p.halo_db + (long long)(i - (p.step_lo - p.nhalo)) * p.npasses * p.n;
+  };
   // stitched value of this element in pass ps (K:643-650): the first covering step raw, every later one halved in
   auto stitched = [&](int ps) {
-    const float* db = p.step_db + (long long)ps * p.nsteps * p.n;
-    float c = db[(long long)i0 * p.n + (e - i0 * p.hop)];
-    for (int i = i0 + 1; i <= i1; ++i) c = (c + db[(long long)i * p.n + (e - i * p.hop)]) * 0.5f;
+    long long st;
+    const float* b0 = band(i0, st);
+    float c = b0[ps * st + (e - i0 * p.hop)];
+    for (int i = i0 + 1; i <= i1; ++i) {
+      const float* bi = band(i, st);
+      c = (c + bi[ps * st + (e - i * p.hop)]) * 0.5f;
+    }
     return c;
   };
   constexpr int AHEAD = 32;  // passes whose loads are in flight per thread (a batch has few elements but many passes)
   float nxt[AHEAD];
   const int ncover = i1 - i0 + 1;                       // steps covering this element: 1 or 2 at the usual hop of N/2
-  const long long o0 = (long long)i0 * p.n + (e - i0 * p.hop), o1 = o0 + p.n - p.hop;
-  const long long pstride = (long long)p.nsteps * p.n;
+  long long sa = 0, sb = 0;
+  const float* pa = p.step_db;
+  const float* pb = p.step_db;
+  if (covered) {
+    pa = band(i0, sa) + (e - i0 * p.hop);
+    if (ncover >= 2) pb = band(i0 + 1, sb) + (e - (i0 + 1) * p.hop);
+  }
   for (int ps0 = 0; ps0 < p.npasses; ps0 += AHEAD) {
     if (covered && !p.base_is_raw) {
       if (ncover <= 2) {
@@ -732,8 +755,8 @@ __global__ __launch_bounds__(256) void scan_stitch_kernel(const StitchParams p) 
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) {
           const bool in = ps0 + u < p.npasses;
-          a[u] = in ? p.step_db[(ps0 + u) * pstride + o0] : 0.f;
-          b[u] = in && ncover == 2 ? p.step_db[(ps0 + u) * pstride + o1] : 0.f;
+          a[u] = in ? pa[(ps0 + u) * sa] : 0.f;
+          b[u] = in && ncover == 2 ? pb[(ps0 + u) * sb] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) nxt[u] = ncover == 2 ? (a[u] + b[u]) * 0.5f : a[u];
@@ -755,9 +778,10 @@ __global__ __launch_bounds__(256) void scan_stitch_kernel(const StitchParams p) 
         } else {
           // every covering step, in order, folds its own spectrum in (pass 0: Avg is overwritten by each step)
           cur = stitched(ps);
-          const float* db = p.step_db + (long long)ps * p.nsteps * p.n;
           for (int i = i0; i <= i1; ++i) {
-            const float x = db[(long long)i * p.n + (e - i * p.hop)];
+            long long st;
+            const float* bi = band(i, st);
+            const float x = bi[ps * st + (e - i * p.hop)];
             if (p.b_max) mx = nan_max(mx, x);
             if (p.b_min) mn = nan_min(mn, x);
             av = first ? x : (av + x) * 0.5f;
@@ -894,6 +918,39 @@ __global__ __launch_bounds__(64) void rowmax_rows_kernel(const float* src, const
     nan |= __shfl_xor(nan, m);
   }
   if (lane == 0) ring[(long long)((row0 + blockIdx.y) % HM_ROWS) * cells + c] = nan ? __builtin_nanf("") : hv;
+}
+
+// Band-sharded scan: the same row reduction over the elements [e_lo, e_hi) this engine owns only -- a PARTIAL row
+// (-inf where the engine owns nothing of a cell); scan_merge_rows_kernel combines the engines' partial rows.
+__global__ __launch_bounds__(64) void rowmax_rows_range_kernel(const float* src, const float* adj, int cells, int g, int e_lo,
+                                                               int e_hi, float* rows) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const long long total = (long long)cells * g;
+  const float* row = src + (long long)blockIdx.y * total;
+  const int lo = max(c * g, e_lo), hi = min((c + 1) * g, e_hi);
+  float hv = -__builtin_inff();
+  int nan = 0;
+  for (int i = lo + lane; i < hi; i += 64) {
+    float v = row[i];
+    if (adj) v -= adj[i];
+    nan |= v != v;
+    hv = fmaxf(hv, v);
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    hv = fmaxf(hv, __shfl_xor(hv, m));
+    nan |= __shfl_xor(nan, m);
+  }
+  if (lane == 0) rows[(long long)blockIdx.y * cells + c] = nan ? __builtin_nanf("") : hv;
+}
+
+// gathered = [world][rows][cells] partial rows in rank order -> ring row (row0 + r) % 128, NaN-propagating max
+__global__ void scan_merge_rows_kernel(const float* gathered, int world, int rows, int cells, float* ring, int row0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cells) return;
+  float v = gathered[i];
+  for (int w = 1; w < world; ++w) v = nan_max(v, gathered[(long long)w * rows * cells + i]);
+  const int r = i / cells, c = i - r * cells;
+  ring[(long long)((row0 + r) % HM_ROWS) * cells + c] = v;
 }
 
 // out[c] = max_{i<g} (src[c*g+i] - adj[c*g+i])

@@ -19,6 +19,7 @@ rank order makes the result bit-identical on every rank and from run to run, whi
 promise.  merge_partials/merge_ring are the same algebra as separate all-reduces on plain tensors
 (device agnostic: tested on CPU with gloo), and merge_gathered_reference restates the kernel in torch.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -90,8 +91,9 @@ def merge_gathered_reference(gathered, n, hm_w, idx0, frames_per_rank):
 
 
 class ShardedZeroSpan:
-    """Drives one engine per rank; with world == 1 it is a plain frames_dev call.  Stream contract: every step
-    re-points the engine at torch's current stream (_follow_current_stream), the stream RCCL orders against."""
+    """Drives one engine per rank; with world == 1 it is a plain frames_dev call on the engine's own stream.  Stream
+    contract of the collective path: every step points the engine at torch's current stream (_follow_current_stream),
+    the stream RCCL orders against."""
 
     def __init__(self, engine, rank=0, world=1, group=None, always_collective=False):
         self.eng, self.rank, self.world, self.group = engine, rank, world, group
@@ -104,11 +106,11 @@ class ShardedZeroSpan:
     def step(self, iq, fmt, frames, cur_db=None, hm_rows=None):
         """Every rank passes its own `frames` capture blocks (its time chunk of a world*frames run)."""
         eng = self.eng
-        _follow_current_stream(eng)
         if not self.collective:
             eng.frames_dev(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
             self.hm_index = (self.hm_index + frames) % HM_ROWS
             return
+        _follow_current_stream(eng)
         total = frames * self.world
         eng.set_hm_index((self.hm_index + self.rank * frames) % HM_ROWS)
         eng.frames_dev(iq, fmt, frames, first_index=self.rank * frames, total_frames=total,
@@ -123,7 +125,7 @@ class ShardedZeroSpan:
 
 
 # ------------------------------------------------------------------------------------------------
-# Frequency-band sharding of a scan pass (BASELINE config 4)
+# Frequency-band sharding of a scan (BASELINE configs 3 and 4)
 def step_range(nsteps, rank, world):
     """Contiguous, balanced share of the tuned bands of one pass: [lo, hi)."""
     lo = (nsteps * rank) // world
@@ -131,59 +133,152 @@ def step_range(nsteps, rank, world):
     return lo, hi
 
 
-def gather_steps(local, nsteps, rank, world, group=None):
-    """local: float32[hi-lo, N] per-step spectra of this rank's bands (or [P, hi-lo, N] for a batch of P passes)
-    -> float32[nsteps, N] ([P, nsteps, N]) on every rank.  Shares differ by at most one step, so every rank pads
-    to the largest share and ONE all-gather moves the whole batch."""
-    if world == 1:
-        return local
-    squeeze = local.dim() == 2
-    if squeeze:
-        local = local.unsqueeze(0)
-    npasses, mine, n = local.shape
-    most = max(step_range(nsteps, r, world)[1] - step_range(nsteps, r, world)[0] for r in range(world))
-    pad = torch.zeros((npasses, most, n), dtype=local.dtype, device=local.device)
-    pad[:, :mine] = local
-    recv = torch.empty((world,) + tuple(pad.shape), dtype=local.dtype, device=local.device)
-    all_gather_flat(recv.view(world, -1), pad.view(-1), group)
-    out = torch.empty((npasses, nsteps, n), dtype=local.dtype, device=local.device)
+def halo_plan(nsteps, world, fft_size, hop):
+    """Who needs which band.  Rank r owns bands [lo_r, hi_r) and the stitched elements from lo_r*hop on; the
+    reference averages every band's lower part with the upper part of the bands before it (K:643-650), so rank r also
+    needs the nhalo = ceil(N/hop) - 1 bands in front of lo_r (1 at the usual hop of N/2) -- and of band j only the
+    columns from (lo_r - j)*hop on.  Returns per rank {'recv': [(src, band, col0)], 'send': [(dst, band, col0)]}."""
+    reach = -(-fft_size // hop) - 1
+    owner = []
     for r in range(world):
         lo, hi = step_range(nsteps, r, world)
-        out[:, lo:hi] = recv[r, :, :hi - lo]
-    return out[0] if squeeze else out
+        owner += [r] * (hi - lo)
+    plan = [{"recv": [], "send": []} for _ in range(world)]
+    for r in range(world):
+        lo, _ = step_range(nsteps, r, world)
+        for j in range(max(0, lo - reach), lo):
+            col0 = (lo - j) * hop
+            plan[r]["recv"].append((owner[j], j, col0))
+            plan[owner[j]]["send"].append((r, j, col0))
+    return plan
 
 
 def _follow_current_stream(eng):
     """torch.distributed collectives are ordered against torch's CURRENT stream; libksa launches on the engine's
-    stream.  Both must be the same stream, or the all-gather could read the exchange block before the kernels that
-    fill it have run (and the merge could read the receive buffer before the gather lands).  The sharded drivers
-    therefore re-point the engine at torch's current stream at every call -- callers may switch streams freely."""
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    stream.  Both must be the same stream, or a collective could read a block before the kernels that fill it have
+    run.  The sharded drivers therefore point the engine at torch's current stream before a step that communicates
+    (ksa_set_stream orders the new stream behind work still queued on the old one); a step without a collective
+    leaves the engine's stream alone."""
+    if torch.cuda.is_available():
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+
+def _p2p(ops_send, ops_recv, group=None):
+    """Post every receive and send of one exchange at once and wait for all of them.  ops_*: [(tensor, peer)].
+    NCCL (= RCCL) moves device tensors directly; gloo (CPU rehearsals, several ranks on one GPU) goes through host
+    copies of device tensors."""
+    if not ops_send and not ops_recv:
+        return
+    if dist.get_backend(group) == "nccl":
+        ops = [dist.P2POp(dist.irecv, t, peer, group) for t, peer in ops_recv]
+        ops += [dist.P2POp(dist.isend, t, peer, group) for t, peer in ops_send]
+        for r in dist.batch_isend_irecv(ops):     # one ncclGroupStart/End: no ordering between the pairs
+            r.wait()
+        return
+    staged, reqs = [], []
+    for t, peer in ops_recv:
+        buf = torch.empty(t.shape, dtype=t.dtype) if t.is_cuda else t
+        staged.append((t, buf))
+        reqs.append(dist.irecv(buf, src=peer, group=group))
+    for t, peer in ops_send:
+        reqs.append(dist.isend(t.cpu() if t.is_cuda else t, dst=peer, group=group))
+    for r in reqs:
+        r.wait()
+    for t, buf in staged:
+        if buf is not t:
+            t.copy_(buf)
 
 
 class ShardedScan:
-    """Scan passes over G GPUs: the steps (tuned bands, each with its own IQ capture) are independent up to
-    their dB spectrum (K:636-641), so rank r transforms steps [lo, hi) of every pass; one all-gather of
-    float32[passes][steps][N] per batch (153 KiB per pass at quickFullScan, 1.1 MiB at fmScan) hands every rank the
-    whole batch and each rank runs the stitch + Max/Min/Avg + waterfall-row kernels on it (K:643-668, K:696-697)
-    -- identical state everywhere, no second collective.  Stream contract: see _follow_current_stream."""
+    """Scan passes over G GPUs, sharded by the STITCHED RANGE: rank r transforms the tuned bands [lo, hi) of every
+    pass (each band has its own IQ capture, K:636-641) and owns the elements [lo*hop, hi*hop) of Fft.Cur/Max/Min/Avg
+    (the last rank up to totalEntries).  Per batch of passes it receives from its left neighbour(s) the overlap part
+    of the band(s) in front of its first one (halo send/recv: (N - hop) floats per pass at the usual hop of N/2 --
+    32 KiB at fmScan), stitches and accumulates its own elements only (ksa_scan_stitch_range_dev), and ONE all-gather of
+    the partial waterfall rows ([min(passes,128)][W] floats per rank) completes the ring on every rank
+    (ksa_scan_merge_rows_dev).  The curves stay sharded until someone reads them (gather_state).  Buffers are
+    allocated once per (nsteps, npasses)."""
 
-    def __init__(self, engine, rank=0, world=1, group=None):
+    def __init__(self, engine, rank=0, world=1, group=None, device=None):
         self.eng, self.rank, self.world, self.group = engine, rank, world, group
+        self.device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+        self._key = None
 
-    def run_pass(self, iq_local, fmt, nsteps):
+    def _setup(self, nsteps, npasses):
+        eng = self.eng
+        self._key = (nsteps, npasses)
+        self.lo, self.hi, self.nhalo, self.e_lo, self.e_hi = eng.scan_shard(nsteps, self.rank, self.world)
+        mine, n = self.hi - self.lo, eng.fft_size
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.own = torch.empty((npasses, max(mine, 1), n), **f32)
+        self.halo = torch.zeros((max(self.nhalo, 1), npasses, n), **f32)          # band major
+        plan = halo_plan(nsteps, self.world, n, eng.scan_hop)[self.rank]
+        self.recv = [(src, j, c0, torch.empty((npasses, n - c0), **f32)) for src, j, c0 in plan["recv"]]
+        self.send = [(dst, j, c0, torch.empty((npasses, n - c0), **f32)) for dst, j, c0 in plan["send"]]
+        self.rows = min(npasses, HM_ROWS)
+        self.rows_all = torch.empty((self.world, self.rows * eng.scan_hm_width), **f32)
+        self.halo_bytes_in = sum(t.numel() * 4 for *_, t in self.recv)
+        self.halo_bytes_out = sum(t.numel() * 4 for *_, t in self.send)
+
+    def collective_bytes(self):
+        """Bytes this rank sends / receives per batch: halo P2P and its share of the row all-gather."""
+        row = self.rows * self.eng.scan_hm_width * 4
+        return {"halo_send": self.halo_bytes_out, "halo_recv": self.halo_bytes_in, "rows_allgather_send": row,
+                "rows_allgather_recv": row * (self.world - 1)}
+
+    def run_pass(self, iq_local, fmt, nsteps, step_ok=None):
         """iq_local: this rank's capture blocks, [hi-lo] frames of fullSize samples, on its GPU."""
-        self.run_passes(iq_local, fmt, nsteps, 1)
+        self.run_passes(iq_local, fmt, nsteps, 1, step_ok)
 
-    def run_passes(self, iq_local, fmt, nsteps, npasses):
-        """iq_local: [npasses][hi-lo] capture blocks of this rank (pass-major), on its GPU."""
+    def run_passes(self, iq_local, fmt, nsteps, npasses, step_ok=None):
+        """iq_local: [npasses][hi-lo] capture blocks of this rank (pass-major), on its GPU.  step_ok (optional):
+        [npasses][hi-lo], 0 marks a band whose tune failed -> dummy ones (K:637-639)."""
         from ._lib import OUT_DB_CLIP
         eng = self.eng
-        _follow_current_stream(eng)
-        lo, hi = step_range(nsteps, self.rank, self.world)
-        mine = hi - lo
-        local = torch.empty((npasses, max(mine, 1), eng.fft_size), dtype=torch.float32, device="cuda")
+        if self._key != (nsteps, npasses):
+            self._setup(nsteps, npasses)
+        mine, n = self.hi - self.lo, eng.fft_size
+        if self.world > 1:
+            _follow_current_stream(eng)
         if mine > 0:
-            eng.curscan_dev(iq_local, fmt, npasses * mine, local, out_mode=OUT_DB_CLIP)
-        full = gather_steps(local[:, :mine], nsteps, self.rank, self.world, self.group)
-        eng.scan_stitch_dev(full.contiguous(), nsteps, npasses)
+            eng.curscan_dev(iq_local, fmt, npasses * mine, self.own, out_mode=OUT_DB_CLIP)
+            if step_ok is not None:
+                bad = torch.as_tensor(np.asarray(step_ok).reshape(npasses, mine) == 0, device=self.own.device)
+                if bool(bad.any()):
+                    self.own[:, :mine][bad] = float(10.0 * np.log10(max(1.0, eng.min_amp)) - eng.gain)
+        if self.world == 1:
+            eng.scan_stitch_dev(self.own, nsteps, npasses)
+            return
+        # halo: the overlap columns of the bands in front of my first one, straight from their owners
+        for _, j, c0, buf in self.send:
+            buf.copy_(self.own[:, j - self.lo, c0:])
+        _p2p([(buf, dst) for dst, _, _, buf in self.send], [(buf, src) for src, _, _, buf in self.recv], self.group)
+        for _, j, c0, buf in self.recv:
+            self.halo[j - (self.lo - self.nhalo), :, c0:] = buf
+        eng.scan_stitch_range_dev(self.own if mine > 0 else None, self.halo if self.nhalo > 0 else None, self.nhalo,
+                                  self.lo, self.hi, nsteps, npasses, self.e_lo, self.e_hi)
+        rows = torch.as_tensor(eng.scan_rows(), device=self.device).reshape(-1)
+        all_gather_flat(self.rows_all, rows, self.group)
+        eng.scan_merge_rows(self.rows_all, self.world, self.rows, npasses)
+
+    def gather_state(self, nsteps):
+        """The plotting hand-off on every rank: the four curves assembled from the ranks' slices (one all-gather of
+        the padded slices, on demand -- not part of a step) + the complete waterfall ring."""
+        eng = self.eng
+        st = eng.scan_state()
+        if self.world == 1:
+            return st
+        if self._key is None or self._key[0] != nsteps:
+            self._setup(nsteps, self._key[1] if self._key else 1)
+        shards = [eng.scan_shard(nsteps, r, self.world) for r in range(self.world)]
+        most = max(s[4] - s[3] for s in shards)
+        mine = torch.zeros((4, most), dtype=torch.float64)
+        for k, name in enumerate(("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg")):
+            mine[k, :self.e_hi - self.e_lo] = torch.from_numpy(st[name][self.e_lo:self.e_hi])
+        send = mine.to(self.device) if dist.get_backend(self.group) == "nccl" else mine
+        every = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(every, send, group=self.group)
+        for r, (_, _, _, e_lo, e_hi) in enumerate(shards):
+            for k, name in enumerate(("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg")):
+                st[name][e_lo:e_hi] = every[r][k, :e_hi - e_lo].cpu().numpy()
+        return st

@@ -221,12 +221,24 @@ class SpectrumEngine:
     def set_flags(self, b_max=True, b_min=True, b_avg=True):
         check(lib.ksa_set_flags(self._h, int(b_max), int(b_min), int(b_avg)))
 
-    def set_adj(self, adj):
+    def set_adj(self, adj, scan=None):
+        """d['Fft.Adj'] (K:400-411).  scan: False = the zeroSpan baseline (fftSize entries), True = the scan baseline
+        (totalEntries entries); None picks by length and, when a one-band scan makes both lengths equal, sets both.
+        adj None clears (both targets when scan is None)."""
         if adj is None:
-            check(lib.ksa_set_adj(self._h, None, 0))
+            for target in ((0, 1) if scan is None else (int(bool(scan)),)):
+                if target == 0 or self.scan_total:
+                    check(lib.ksa_set_adj(self._h, target, None, 0))
             return
         a = np.ascontiguousarray(adj, dtype=np.float32)
-        check(lib.ksa_set_adj(self._h, _ptr(a), a.size))
+        if scan is None:
+            targets = [t for t, n in ((0, self.fft_size), (1, self.scan_total)) if n and a.size == n]
+            if not targets:
+                raise KsaError("adj length %d matches neither fftSize %d nor totalEntries %d" % (a.size, self.fft_size, self.scan_total))
+        else:
+            targets = [int(bool(scan))]
+        for t in targets:
+            check(lib.ksa_set_adj(self._h, t, _ptr(a), a.size))
 
     def reset(self):
         check(lib.ksa_reset_state(self._h))
@@ -260,8 +272,47 @@ class SpectrumEngine:
             ok = np.ascontiguousarray(step_ok, dtype=np.uint8)
         check(lib.ksa_scan_pass_dev(self._h, _ptr(iq), fmt, stride, int(nsteps), _ptr(ok)))
 
+    def scan_pass(self, blocks, step_ok=None):
+        """One pass from HOST memory (K:621-668 + K:696-697): blocks = [nsteps][fullSize] complex64, or
+        [nsteps][2*fullSize] uint8 I,Q; staged through an engine-owned device buffer (ksa_scan_pass_c64 / _u8)."""
+        a = np.asarray(blocks)
+        if a.dtype == np.uint8:
+            a, fn, per = np.ascontiguousarray(a), lib.ksa_scan_pass_u8, 2 * self.full_size
+        else:
+            a, fn, per = np.ascontiguousarray(a, dtype=np.complex64), lib.ksa_scan_pass_c64, self.full_size
+        if a.ndim != 2 or a.shape[1] != per:
+            raise KsaError("scan_pass wants [nsteps][%d] %s, got %s" % (per, a.dtype, a.shape))
+        ok = None if step_ok is None else np.ascontiguousarray(step_ok, dtype=np.uint8)
+        if ok is not None and ok.size != a.shape[0]:
+            raise KsaError("step_ok has %d entries for %d steps" % (ok.size, a.shape[0]))
+        check(fn(self._h, _ptr(a), int(a.shape[0]), _ptr(ok)))
+
     def scan_stitch_dev(self, step_db, nsteps, npasses=1):
         check(lib.ksa_scan_stitch_passes_dev(self._h, _ptr(step_db), int(nsteps), int(npasses)))
+
+    # band-sharded scan (SURVEY 8e): this engine owns bands [step_lo, step_hi) and elements [elem_lo, elem_hi)
+    def scan_shard(self, nsteps, rank, world):
+        """(step_lo, step_hi, nhalo, elem_lo, elem_hi) of rank `rank` of `world`: contiguous balanced bands, the
+        elements from its first band's start up to the next rank's (the last rank: up to totalEntries), and the
+        number of bands in front of its own that still cover its elements (ceil(N/hop) - 1, at most step_lo)."""
+        lo, hi = (nsteps * rank) // world, (nsteps * (rank + 1)) // world
+        e_hi = self.scan_total if rank == world - 1 else min(self.scan_total, hi * self.scan_hop)
+        e_lo = min(lo * self.scan_hop, e_hi)
+        nhalo = min(lo, -(-self.fft_size // self.scan_hop) - 1)
+        return lo, hi, nhalo, e_lo, e_hi
+
+    def scan_stitch_range_dev(self, own_db, halo_db, nhalo, step_lo, step_hi, nsteps, npasses, elem_lo, elem_hi):
+        check(lib.ksa_scan_stitch_range_dev(self._h, _ptr(own_db), _ptr(halo_db), int(nhalo), int(step_lo), int(step_hi),
+                                            int(nsteps), int(npasses), int(elem_lo), int(elem_hi)))
+
+    def scan_rows(self):
+        """Device view float32[rows, W] of the partial waterfall rows of the last scan_stitch_range_dev."""
+        p, r = C.c_void_p(), C.c_int32()
+        check(lib.ksa_scan_rows_dev(self._h, C.byref(p), C.byref(r)))
+        return DevArray(p.value, (r.value, self.scan_hm_width), self)
+
+    def scan_merge_rows(self, gathered, world, rows, npasses):
+        check(lib.ksa_scan_merge_rows_dev(self._h, _ptr(gathered), int(world), int(rows), int(npasses)))
 
     def scan_passes_dev(self, iq, fmt, nsteps, npasses, step_ok=None, frame_stride=None):
         """A batch of captured passes ([npasses][nsteps] blocks) in one call: same state as pass-by-pass calls."""
@@ -314,3 +365,56 @@ class SpectrumEngine:
         ms, n = C.c_double(), C.c_int64()
         check(lib.ksa_prof_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+# ---- several engines of ONE process (one per GPU of the node, or several on one GPU): no torch, no RCCL ----------
+def _handles(engines):
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    return arr, len(engines)
+
+
+def allreduce_state(engines, frames_per_rank, hm_index0=0):
+    """SURVEY 8(b) allreduce_state(handles[], n): merge the uncommitted time chunks of `engines` (rank order) so that
+    every engine ends with the state of the whole run (ksa_allreduce_state)."""
+    arr, n = _handles(engines)
+    check(lib.ksa_allreduce_state(arr, n, int(frames_per_rank), int(hm_index0)))
+
+
+def scan_allstitch(engines, own_db, nsteps, npasses):
+    """Band-sharded scan inside one process: own_db[r] = device float32[npasses][bands of rank r][N] of engine r
+    (bands split as nsteps*r/n .. nsteps*(r+1)/n): halo copies, range stitch, waterfall-row merge."""
+    arr, n = _handles(engines)
+    ptrs = (C.c_void_p * n)(*[(_ptr(b).value if b is not None else None) for b in own_db])
+    check(lib.ksa_scan_allstitch(arr, n, ptrs, int(nsteps), int(npasses)))
+
+
+def scan_gather_state(engines, nsteps):
+    """The four stitched curves assembled from the engines' owned slices: dict of float64[totalEntries]."""
+    arr, n = _handles(engines)
+    t = engines[0].scan_total
+    bufs = [np.empty(t, dtype=np.float32) for _ in range(4)]
+    check(lib.ksa_scan_gather_state(arr, n, int(nsteps), *[_ptr(b) for b in bufs]))
+    return {k: b.astype(np.float64) for k, b in zip(("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg"), bufs)}
+
+
+class PinnedBuffer:
+    """Page-locked host memory from ksa_host_alloc as a numpy array (capture blocks copy faster from it)."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(int(x) for x in shape), np.dtype(dtype)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._p = C.c_void_p()
+        check(lib.ksa_host_alloc(C.byref(self._p), nbytes))
+        self.array = np.frombuffer((C.c_char * nbytes).from_address(self._p.value), dtype=self.dtype).reshape(self.shape)
+
+    def close(self):
+        if getattr(self, "_p", None) and self._p.value:
+            self.array = None
+            lib.ksa_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

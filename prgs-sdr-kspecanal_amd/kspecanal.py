@@ -222,7 +222,7 @@ def get_engine(d, scan_total=0, max_frames=1):
             scan_non_overlap=d["scanRangeNonOverlap"])
         d["ksa.key"] = key
         if d.get("Fft.Adj") is not None:
-            d["ksa.engine"].set_adj(d["Fft.Adj"])
+            d["ksa.engine"].set_adj(d["Fft.Adj"], scan=bool(scan_total))
     return d["ksa.engine"]
 
 
@@ -565,7 +565,6 @@ def scan_geometry(d):
 def scan_range(d):
     """K:712-732 with _scan_range (K:568-698): per pass, capture every tuned band, then one device call
     stitches the bands and updates Cur/Max/Min/Avg and the waterfall row."""
-    import torch
     _fixupfreqs_scanrange(d)
     groups, total, centers = scan_geometry(d)
     print("_scanRange: start:{} end:{} samplingRate:{}".format(d["startFreq"], d["endFreq"], d["samplingRate"]))
@@ -579,8 +578,9 @@ def scan_range(d):
     span = groups * d["samplingRate"]
     d["freqsAll"] = np.fft.fftshift(np.fft.fftfreq(total, 1 / span) + d["startFreq"] + span / 2)   # K:609
     u8 = d["iqFormat"] == "u8" and hasattr(d["sdr"], "read_bytes")
-    stage = torch.empty((steps, d["fullSize"] * 2), dtype=torch.uint8 if u8 else torch.float32).pin_memory()
-    dev = torch.empty_like(stage, device="cuda:%d" % d["device"])
+    # one pass of capture blocks in page-locked host memory; the library stages it to the GPU (ksa_scan_pass_c64 / _u8)
+    stage = _engine.PinnedBuffer((steps, d["fullSize"] * 2) if u8 else (steps, d["fullSize"]), np.uint8 if u8 else np.complex64)
+    blocks = stage.array
     prev = time.time()
     for i in range(d["prgLoopCnt"]):
         if d["cmd.stop"]:
@@ -594,17 +594,16 @@ def scan_range(d):
                 print("WARN:_scanRange: Dummy data for {} to {}".format(fc - d["samplingRate"] / 2, fc + d["samplingRate"] / 2))
                 ok[s] = 0                                                   # K:637-639
                 continue
-            blk = sdr_read(d, d["fullSize"])
-            stage[s].copy_(torch.from_numpy(blk if u8 else blk.view(np.float32)))
-        dev.copy_(stage, non_blocking=False)
+            blocks[s] = sdr_read(d, d["fullSize"])
         eng.set_flags(d["bDataMax"], d["bDataMin"], True)
-        eng.scan_pass_dev(dev, FMT_U8 if u8 else FMT_C64, steps, step_ok=ok)
+        eng.scan_pass(blocks, step_ok=ok)
         st = eng.scan_state()
         for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg"):
             d[k] = st[k]
         d["fftHM"], d["fftHMIndex"] = st["fftHM"], st["hm_index"]
         _plot_levels(d, d["freqsAll"], d["Fft.Cur"], eng, scan=True)
         _plot_heatmap(d, d["fftHM"])
+    stage.close()
 
 
 # ------------------------------------------------------------------------------------------------ main

@@ -18,6 +18,7 @@ from conftest import load_pkg, ROOT
 N, FULL, Q, GAIN, XRES = 256, 2048, 0.5, 19.1, 64
 
 
+
 def _partial_from_oracle(db, first_index, total, has_prev, owns_last):
     """[max, cur-or--inf, -min, sum_k 2^-(n-k+1) x_k] -- what accumulate_partial/reduce leave on a rank."""
     f, n = db.shape
@@ -78,10 +79,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("frames_per_rank,idx0", [(5, 0), (70, 100), (200, 17)])
-def test_two_rank_merge_equals_sequential_run(tmp_path, frames_per_rank, idx0):
+@pytest.mark.parametrize("world,frames_per_rank,idx0", [(2, 5, 0), (2, 70, 100), (2, 200, 17), (3, 50, 9), (8, 12, 120), (8, 40, 3)])
+def test_time_chunk_merge_equals_sequential_run(tmp_path, world, frames_per_rank, idx0):
+    """2, 3 and 8 ranks (the node size): ring ownership when the last 128 frames span 4 ranks (8 x 40) and when the
+    whole run is shorter than the ring (8 x 12)."""
     load_pkg()
-    world = 2
     out = str(tmp_path / "merged.npz")
     mp.spawn(_worker, args=(world, _free_port(), frames_per_rank, idx0, out), nprocs=world, join=True)
     got = np.load(out)
@@ -118,56 +120,158 @@ def test_ring_owner_map():
 
 
 # ------------------------------------------------------------------------------------------ scan band shard
-def _scan_worker(rank, world, port, out_path):
+class FakeScanEngine:
+    """CPU stand-in for SpectrumEngine in the band-sharded scan driver (test infrastructure: numpy + the oracle).
+    It restates what libksa does per rank -- clipped dB spectra of its bands, the range stitch over the elements it
+    owns (K:643-668) and the partial waterfall rows (K:696-697) -- so that distributed.ShardedScan's message plan
+    (halo send/recv, row all-gather, gather_state) can run with 2, 3 and 8 gloo ranks without a GPU."""
+
+    def __init__(self, n, full, q_win, window, gain, min_amp, xres, total, scan_q):
+        self.fft_size, self.full_size, self.q_win, self.gain, self.min_amp = n, full, q_win, gain, min_amp
+        self.win = orc.window_table(window, n)
+        self.scan_total, self.scan_hop, self.scan_hm_width = total, int(n * scan_q), xres
+        floor = 10 * np.log10(min_amp) - gain
+        self.state = np.stack([np.full(total, floor), np.full(total, floor), np.full(total, -gain), np.full(total, floor)])
+        self.hm = np.full((128, xres), min_amp)
+        self.hm_index, self.passes, self._rows = 0, 0, None
+
+    def scan_shard(self, nsteps, rank, world):
+        return load_pkg().SpectrumEngine.scan_shard(self, nsteps, rank, world)
+
+    def set_stream(self, s):
+        pass
+
+    def curscan_dev(self, iq, fmt, nframes, out, out_mode=None):
+        x = iq.numpy().reshape(nframes, self.full_size, 2)
+        o = out.view(-1, self.fft_size)
+        for f in range(nframes):
+            lin = orc.curscan(x[f, :, 0] + 1j * x[f, :, 1], self.fft_size, self.q_win, self.win, "AVG")
+            o[f] = torch.from_numpy(orc.log_no_gain(orc.clip2minamp(lin, self.min_amp), self.gain, inf_to=0).astype(np.float32))
+
+    def scan_stitch_range_dev(self, own, halo, nhalo, lo, hi, nsteps, npasses, e_lo, e_hi):
+        n, hop, tot = self.fft_size, self.scan_hop, self.scan_total
+        own = None if own is None else own.numpy().astype(np.float64)
+        halo = None if halo is None else halo.numpy().astype(np.float64)
+        band = lambda ps, i: own[ps, i - lo] if i >= lo else halo[i - (lo - nhalo), ps]
+        rows = min(npasses, 128)
+        self._rows = np.full((rows, self.scan_hm_width), -np.inf)
+        g = tot // self.scan_hm_width
+        for ps in range(npasses):
+            for e in range(e_lo, e_hi):
+                i0 = 0 if e - n + 1 <= 0 else (e - n + hop) // hop
+                i1 = min(e // hop, nsteps - 1)
+                if i0 > i1:
+                    continue
+                c = band(ps, i0)[e - i0 * hop]
+                for i in range(i0 + 1, i1 + 1):
+                    c = (c + band(ps, i)[e - i * hop]) * 0.5
+                cur, mx, mn, av = self.state[:, e]
+                first = self.passes == 0 and ps == 0
+                self.state[:, e] = (c, max(mx, c), min(mn, c), c if first else (av + c) * 0.5)
+            if ps >= npasses - rows and e_hi > e_lo:
+                r = ps - (npasses - rows)
+                for cell in range(self.scan_hm_width):
+                    a, b = max(cell * g, e_lo), min((cell + 1) * g, e_hi)
+                    if b > a:
+                        self._rows[r, cell] = self.state[3, a:b].max()
+        self.passes += npasses
+        self._npasses = npasses
+
+    def scan_rows(self):
+        return torch.from_numpy(self._rows.astype(np.float32))
+
+    def scan_merge_rows(self, gathered, world, rows, npasses):
+        m = gathered.numpy().reshape(world, rows, self.scan_hm_width).max(axis=0)
+        for r in range(rows):
+            self.hm[(self.hm_index + npasses - rows + r) % 128] = m[r]
+        self.hm_index = (self.hm_index + npasses) % 128
+
+    def scan_state(self):
+        out = {k: self.state[i].copy() for i, k in enumerate(("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg"))}
+        out.update(fftHM=self.hm.copy(), hm_index=self.hm_index, passes=self.passes)
+        return out
+
+
+SCAN_CASES = {   # name: n, scanRangeNonOverlap, bands of 2.4 MHz, passes per batch
+    "half": (64, 0.5, 9, 3),        # 18 bands like fmScan: shares of 2-3 at 8 ranks
+    "eighth": (64, 0.125, 2, 2),    # halo of 7 bands: spans several ranks at 8 ranks
+    "whole": (32, 1.0, 11, 2),      # hop == N: no halo at all
+    "tiny": (32, 0.5, 2, 2),        # 4 bands over 8 ranks: half of the ranks own nothing
+}
+
+
+def _scan_case(name):
+    n, q, bands, passes = SCAN_CASES[name]
+    fs, start = 2.4e6, 100e6
+    end = start + bands * fs
+    steps = len(orc.scan_steps(start, end, fs, q))
+    full = 8 * n
+    x = orc.synth_iq(full * steps * passes * 2, 77).astype(np.complex64).reshape(2, passes, steps, full)
+    return n, q, fs, start, end, steps, full, passes, x
+
+
+def _sharded_scan_worker(rank, world, port, name, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ksa_dist = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
-    n, full, steps = 64, 512, 7                                  # 7 steps over 3 ranks: shares 2/2/3
-    x = orc.synth_iq(full * steps, 77).astype(np.complex64).reshape(steps, full)
+    n, q, fs, start, end, steps, full, passes, x = _scan_case(name)
+    total = int((end - start) / fs) * n
+    eng = FakeScanEngine(n, full, 0.5, "hanning", GAIN, 1e-7, 32, total, q)
+    run = ksa_dist.ShardedScan(eng, rank, world, device="cpu")
     lo, hi = ksa_dist.step_range(steps, rank, world)
-    win = orc.window_table("ones", n)
-    local = np.array([orc.curscan(x[s], n, 0.1, win, "AVG") for s in range(lo, hi)], dtype=np.float32).reshape(hi - lo, n)
-    got = ksa_dist.gather_steps(torch.from_numpy(local), steps, rank, world)
-    if rank == world - 1:
-        np.save(out_path, got.numpy())
+    for batch in range(2):
+        iq = torch.view_as_real(torch.from_numpy(np.ascontiguousarray(x[batch][:, lo:hi]))).contiguous()
+        run.run_passes(iq, 0, steps, passes)
+    st = run.gather_state(steps)
+    cb = run.collective_bytes()
+    assert cb["halo_recv"] == sum(passes * (n - c0) * 4 for _, _, c0 in ksa_dist.halo_plan(steps, world, n, eng.scan_hop)[rank]["recv"])
+    np.savez(out_path % rank, hm_index=st["hm_index"], **{k: st[k] for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg", "fftHM")})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_scan_band_shard_gather(tmp_path):
+@pytest.mark.parametrize("name,world", [("half", 2), ("half", 3), ("half", 8), ("eighth", 8), ("whole", 3), ("eighth", 2), ("tiny", 8)])
+def test_band_sharded_scan_driver_over_gloo(tmp_path, name, world):
+    """distributed.ShardedScan with 2 / 3 / 8 ranks on CPU (gloo) over an engine stand-in: after two batches every
+    rank's gathered curves and waterfall ring equal the oracle's sequential scan (K:621-668, K:696-697, K:732)."""
+    load_pkg()
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_sharded_scan_worker, args=(world, _free_port(), name, out), nprocs=world, join=True)
+    n, q, fs, start, end, steps, full, passes, x = _scan_case(name)
+    ref = orc.ScanState(n, start, end, fs, GAIN, 1e-7, 32, scan_non_overlap=q)
+    win = orc.window_table("hanning", n)
+    for batch in range(2):
+        for p in range(passes):
+            ref.run_pass([orc.curscan(x[batch, p, s], n, 0.5, win, "AVG") for s in range(steps)])
+    for r in range(world):
+        got = np.load(out % r)
+        assert int(got["hm_index"]) == ref.hm_index
+        for k, want in (("Fft.Cur", ref.cur), ("Fft.Max", ref.max), ("Fft.Min", ref.min), ("Fft.Avg", ref.avg)):
+            assert np.max(np.abs(got[k] - want)) < 2e-4, (k, r)          # float32 transport of the dB spectra
+        assert np.max(np.abs(got["fftHM"][:2 * passes] - ref.hm[:2 * passes])) < 2e-4, r
+        assert np.allclose(got["fftHM"][2 * passes:], ref.hm[2 * passes:])
+
+
+def test_scan_band_shares_and_halo_plan():
     load_pkg()
     ksa_dist = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
     assert [ksa_dist.step_range(7, r, 3) for r in range(3)] == [(0, 2), (2, 4), (4, 7)]
     assert [ksa_dist.step_range(1226, r, 8)[1] - ksa_dist.step_range(1226, r, 8)[0] for r in range(8)] == [153, 153, 153, 154, 153, 153, 153, 154]
-    out = str(tmp_path / "steps.npy")
-    mp.spawn(_scan_worker, args=(3, _free_port(), out), nprocs=3, join=True)
-    n, full, steps = 64, 512, 7
-    x = orc.synth_iq(full * steps, 77).astype(np.complex64).reshape(steps, full)
-    want = np.array([orc.curscan(x[s], n, 0.1, orc.window_table("ones", n), "AVG") for s in range(steps)], dtype=np.float32)
-    assert np.array_equal(np.load(out), want)
-
-
-def _scan_batch_worker(rank, world, port, out_path):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    sys.path.insert(0, ROOT)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    ksa_dist = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
-    passes, steps, n = 3, 7, 16
-    full = torch.arange(passes * steps * n, dtype=torch.float32).reshape(passes, steps, n)
-    lo, hi = ksa_dist.step_range(steps, rank, world)
-    got = ksa_dist.gather_steps(full[:, lo:hi].contiguous(), steps, rank, world)
-    if rank == 0:
-        np.save(out_path, got.numpy())
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_scan_band_shard_gather_batch_of_passes(tmp_path):
-    """The multi-pass form: every rank holds [passes][its bands][N]; one all-gather rebuilds [passes][steps][N]."""
-    load_pkg()
-    out = str(tmp_path / "batch.npy")
-    mp.spawn(_scan_batch_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    want = np.arange(3 * 7 * 16, dtype=np.float32).reshape(3, 7, 16)
-    assert np.array_equal(np.load(out), want)
+    assert [ksa_dist.step_range(18, r, 8)[1] - ksa_dist.step_range(18, r, 8)[0] for r in range(8)] == [2, 2, 2, 3, 2, 2, 2, 3]
+    # fmScan at 8 ranks: every rank but the first receives the upper half of ONE band from its left neighbour
+    plan = ksa_dist.halo_plan(18, 8, 16384, 8192)
+    assert plan[0]["recv"] == [] and plan[7]["send"] == []
+    for r in range(1, 8):
+        (src, band, col0), = plan[r]["recv"]
+        assert src == r - 1 and band == ksa_dist.step_range(18, r, 8)[0] - 1 and col0 == 8192
+    # every receive has its matching send, in the same order per pair of ranks
+    for nsteps, world, n, hop in ((18, 8, 16384, 8192), (17, 8, 64, 8), (7, 3, 64, 16), (3, 8, 64, 32)):
+        plan = ksa_dist.halo_plan(nsteps, world, n, hop)
+        for r in range(world):
+            for src in range(world):
+                want = [(j, c) for s_, j, c in plan[r]["recv"] if s_ == src]
+                have = [(j, c) for d_, j, c in plan[src]["send"] if d_ == r]
+                assert want == have

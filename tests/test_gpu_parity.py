@@ -81,7 +81,7 @@ def test_curscan_vs_reference_golden(ksa, tag):
 
 
 @pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
-@pytest.mark.parametrize("q", [0.5, 0.1])
+@pytest.mark.parametrize("q", [0.5, 0.25, 0.1])
 def test_curscan_every_plan_size(ksa, n, q):
     full = orc.full_size(n, 2.4e6)
     x = orc.synth_iq(full, 1000 + n).astype(np.complex64)

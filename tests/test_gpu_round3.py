@@ -1,0 +1,375 @@
+"""GPU parity, round 3: the torch-free boundary of include/ksa.h -- ksa_allreduce_state (several engines of one
+process merged by the library), the host-pointer scan pass (ksa_scan_pass_c64 / _u8), the band-sharded scan
+(ksa_scan_stitch_range_dev / ksa_scan_merge_rows_dev / ksa_scan_allstitch), ksa_set_adj's explicit target,
+ksa_set_stream's ordering, pinned host buffers -- all through the C ABI, against the reference-run goldens and the
+oracle.  Tolerances: as test_gpu_parity.py."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ksa_oracle as orc
+from conftest import golden, load_pkg, ROOT
+from test_gpu_parity import assert_db, assert_lin, GAIN
+from test_gpu_round2 import _regen_iq, _scan_engine, _check_sampled, _bench
+
+pytestmark = pytest.mark.gpu
+CURVES = ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+# ------------------------------------------------------------------------------- SURVEY 8(b) allreduce_state
+@pytest.mark.parametrize("world,fpr,idx0,n", [(2, 100, 77, 1024), (3, 40, 0, 4096), (8, 16, 120, 1024), (8, 200, 5, 256)])
+def test_allreduce_state_engines_of_one_process(ksa, torch_cuda, world, fpr, idx0, n):
+    """ksa_allreduce_state: `world` engines (here all on GPU 0; one per GPU on a node) each hold an uncommitted time
+    chunk; afterwards every engine holds the state of a single engine that ran the whole run (K:470-484) -- the same
+    bits on every handle.  Two steps: stale ring rows, the has-previous Avg path and the ring wrap are covered."""
+    torch = torch_cuda
+    full, xres = 4 * n, 128
+    total = world * fpr
+    x = orc.synth_iq(full * total * 2, 131 + world).astype(np.complex64).reshape(2, total, full)
+    dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+    mk = lambda mf: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=xres, max_frames=mf)
+    one = mk(total)
+    one.set_hm_index(idx0)
+    ranks = [mk(fpr) for _ in range(world)]
+    hm_index = idx0
+    for step in range(2):
+        one.frames_dev(dev[step], ksa.FMT_C64, total)
+        for r, eng in enumerate(ranks):
+            eng.set_hm_index((hm_index + r * fpr) % 128)
+            eng.frames_dev(dev[step, r * fpr:(r + 1) * fpr], ksa.FMT_C64, fpr, first_index=r * fpr, total_frames=total, commit=False)
+        ksa.allreduce_state(ranks, fpr, hm_index)
+        hm_index = (hm_index + total) % 128
+        want = one.state()
+        got = [eng.state() for eng in ranks]
+        for r, st in enumerate(got):
+            assert st["frames"] == want["frames"] and st["hm_index"] == want["hm_index"] == hm_index
+            for k in CURVES + ("fftHM",):
+                assert_db(st[k], want[k], what="%s engine %d step %d" % (k, r, step))
+                assert np.array_equal(st[k], got[0][k]), "engine %d differs from engine 0 in %s" % (r, k)
+    for eng in ranks + [one]:
+        eng.close()
+
+
+def test_allreduce_state_refusals(ksa, torch_cuda):
+    torch = torch_cuda
+    n, full = 256, 1024
+    a = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", max_frames=4)
+    b = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", max_frames=4)
+    c = ksa.SpectrumEngine(2 * n, full_size=full, non_overlap=0.5, window="hanning", max_frames=4)
+    with pytest.raises(ksa.KsaError, match="pending"):
+        ksa.allreduce_state([a, b], 4, 0)                    # nothing uncommitted
+    with pytest.raises(ksa.KsaError, match="geometry"):
+        ksa.allreduce_state([a, c], 4, 0)
+    with pytest.raises(ksa.KsaError, match="again"):
+        ksa.allreduce_state([a, a], 4, 0)
+    for e in (a, b, c):
+        e.close()
+
+
+# ------------------------------------------------------------------------------- host-pointer scan pass
+@pytest.mark.parametrize("tag,fmt", [("fm_n16384", "c64"), ("quickfull_n64", "c64"), ("3band_n512", "u8")])
+def test_scan_pass_from_host_memory(ksa, tag, fmt):
+    """ksa_scan_pass_c64 / _u8: the body of the reference's step loop (K:621-668, K:696-697) fed from caller-owned
+    host memory -- the BASELINE fmScan / quickFullScan goldens with no torch tensor anywhere; uint8 against the
+    oracle on the unpacked samples (row A0 is parity-unpinned, see oracle header)."""
+    g = golden("scan_" + tag)
+    n, full, passes, steps = int(g["fft_size"]), int(g["full"]), int(g["passes"]), int(g["steps"])
+    eng = _scan_engine(ksa, g, steps)
+    if fmt == "c64":
+        x = _regen_iq(g, full * steps * passes).reshape(passes, steps, full)
+        for p in range(passes):
+            eng.scan_pass(x[p])
+        st = eng.scan_state()
+        assert st["passes"] == passes and st["hm_index"] == int(g["hm_index"])
+        _check_sampled(st, g, tag)
+        assert_db(st["fftHM"][:passes], g["hm_rows"][:passes], what=tag + " waterfall rows")
+    else:
+        x = g["iq"].reshape(passes, steps, full)
+        raw = np.stack([orc.quantize_u8(x[p].reshape(-1) * 0.8).reshape(steps, 2 * full) for p in range(passes)])
+        win = orc.window_table(str(g["window"]), n)
+        ref = orc.ScanState(n, float(g["start_freq"]), float(g["end_freq"]), float(g["sampling_rate"]), float(g["gain"]),
+                            float(g["min_amp"]), int(g["xres"]), float(g["scan_non_overlap"]))
+        buf = ksa.PinnedBuffer((steps, 2 * full), np.uint8)       # page-locked staging from ksa_host_alloc
+        for p in range(passes):
+            ref.run_pass([orc.curscan(orc.unpack_u8(raw[p, s]), n, float(g["non_overlap"]), win, "AVG") for s in range(steps)])
+            buf.array[:] = raw[p]
+            eng.scan_pass(buf.array)
+        buf.close()
+        st = eng.scan_state()
+        for k in ("cur", "max", "min", "avg"):
+            assert_db(st["Fft." + k.capitalize()], getattr(ref, k), what=tag + " u8 " + k)
+        assert_db(st["fftHM"][:passes], ref.hm[:passes], what=tag + " u8 hm")
+    with pytest.raises(ksa.KsaError, match="nsteps"):
+        eng.scan_pass(np.zeros((steps + 1, full), dtype=np.complex64))
+    eng.close()
+
+
+def test_scan_cli_runs_without_torch(tmp_path):
+    """kspecanal.py's scan mode end to end in a fresh interpreter: torch is never imported (the capture blocks go
+    through ksa_host_alloc + ksa_scan_pass_c64), and the result equals the in-process run."""
+    code = (
+        "import sys, importlib, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "k = importlib.import_module('prgs-sdr-kspecanal_amd.kspecanal')\n"
+        "d = k.main(['scan', 'startFreq', '100e6', 'endFreq', '104.8e6', 'fftSize', '256', 'window', 'hanning', 'source', 'synth',\n"
+        "            'prgLoopCnt', '3', 'bPltLevels', 'false', 'bPltHeatMap', 'false', 'xRes', '64'])\n"
+        "assert 'torch' not in sys.modules, 'scan mode imported torch'\n"
+        "np.save(%r, np.stack([d['Fft.Cur'], d['Fft.Max'], d['Fft.Min'], d['Fft.Avg']]))\n" % (ROOT, str(tmp_path / "scan.npy")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = np.load(str(tmp_path / "scan.npy"))
+    assert got.shape[0] == 4 and np.all(np.isfinite(got))
+    assert np.all(got[1] >= got[2]) and np.all(got[1] >= got[0] - 1e-4)
+
+
+# ------------------------------------------------------------------------------- ksa_set_adj target
+def test_one_band_scan_with_adj_siglvls(ksa, torch_cuda):
+    """A scan over exactly one sampling-rate band has totalEntries == fftSize: the baseline must still reach the scan
+    slot (waterfall rows K:669 + K:697, Levels K:400-411), which the length-based dispatch of ABI 1 missed."""
+    torch = torch_cuda
+    n, full, fs = 256, 2048, 2.4e6
+    start, end = 100e6, 102.4e6
+    centers = orc.scan_steps(start, end, fs, 0.5)
+    steps, passes = len(centers), 3
+    adj = np.linspace(-4.0, 6.0, n)
+    x = orc.synth_iq(full * steps * passes, 61).astype(np.complex64).reshape(passes, steps, full)
+    win = orc.window_table("hanning", n)
+    ref = orc.ScanState(n, start, end, fs, GAIN, 1e-7, 64, adj=adj)
+    assert ref.total == n
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.1, window="hanning", gain=GAIN, min_amp=1e-7, xres=64,
+                             max_frames=steps, scan_total_entries=ref.total)
+    eng.set_adj(adj, scan=True)
+    for p in range(passes):
+        ref.run_pass([orc.curscan(x[p, s], n, 0.1, win, "AVG") for s in range(steps)])
+        eng.scan_pass(x[p])
+    st = eng.scan_state()
+    assert_db(st["fftHM"][:passes], ref.hm[:passes], what="one-band scan, adjusted waterfall rows")
+    lv = eng.levels(64, "MAX", scan=True)
+    want = orc.plotcompress(ref.avg - adj, 64, "MAX")
+    assert_db(lv[3], want, what="one-band scan, adjusted Levels avg")
+    # the zeroSpan slot is a different target: clearing it leaves the scan baseline alone
+    eng.set_adj(None, scan=False)
+    assert_db(eng.levels(64, "MAX", scan=True)[3], want, what="scan baseline survives clearing the zeroSpan one")
+    eng.set_adj(None, scan=True)
+    assert_db(eng.levels(64, "MAX", scan=True)[3], orc.plotcompress(ref.avg, 64, "MAX"), what="cleared")
+    with pytest.raises(ksa.KsaError, match="adj length"):
+        eng.set_adj(np.zeros(n + 1), scan=True)
+    eng.set_adj(adj)                                   # no target given and both lengths equal: both are set
+    assert_db(eng.levels(64, "MAX", scan=True)[3], want, what="both targets")
+    eng.close()
+
+
+# ------------------------------------------------------------------------------- band-sharded scan
+def _own_spectra(ksa, torch, eng, x_dev, passes, steps, lo, hi):
+    """[passes][hi-lo][N] clipped dB spectra of the bands [lo, hi) of every pass (pass-major device block)."""
+    mine = hi - lo
+    own = torch.empty((passes, max(mine, 1), eng.fft_size), dtype=torch.float32, device="cuda")
+    if mine:
+        iq = x_dev[:, lo:hi].contiguous()
+        eng.curscan_dev(iq, ksa.FMT_C64, passes * mine, own, out_mode=ksa.OUT_DB_CLIP)
+    return own
+
+
+@pytest.mark.parametrize("n,q,world,passes,base_raw", [(256, 0.5, 2, 3, False), (64, 0.5, 8, 140, False), (256, 0.25, 3, 5, False),
+                                                        (128, 0.125, 4, 2, False), (512, 0.5, 8, 3, True), (256, 1.0, 3, 4, False)])
+def test_band_sharded_scan_equals_one_engine(ksa, torch_cuda, n, q, world, passes, base_raw):
+    """ksa_scan_allstitch: `world` engines of one process, each owning a contiguous share of the tuned bands and of the
+    stitched range, halo copies between neighbours, partial waterfall rows merged -- against ONE engine that ran the
+    same passes (bit for bit: the per-element arithmetic is the same) and against the oracle (K:621-668, K:696-697).
+    Shares of 1-2 bands at 8 ranks, halos that span several ranks (hop N/8), hop == N (no halo), 140 passes (the
+    ring wraps), two batches (the second continues the state)."""
+    torch = torch_cuda
+    full, fs = 8 * n, 2.4e6
+    start, end = 100e6, 100e6 + 5 * fs
+    centers = orc.scan_steps(start, end, fs, q)
+    steps = len(centers)
+    xres = 64
+    win = orc.window_table("hanning", n)
+    ref = orc.ScanState(n, start, end, fs, GAIN, 1e-7, xres, scan_non_overlap=q, base_is_raw=base_raw)
+    mk = lambda mf: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=1e-7, xres=xres,
+                                       max_frames=mf, scan_total_entries=ref.total, scan_non_overlap=q)
+    one = mk(steps * passes)
+    ranks = [mk(max(1, passes * (-(-steps // world)))) for _ in range(world)]
+    for e in ranks + [one]:
+        e.scan_set_base_is_raw(base_raw)
+    for batch in range(2):
+        x = orc.synth_iq(full * steps * passes, 300 + batch).astype(np.complex64).reshape(passes, steps, full)
+        x_dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+        one.scan_passes_dev(x_dev, ksa.FMT_C64, steps, passes)
+        if passes <= 5:
+            for p in range(passes):
+                ref.run_pass([orc.curscan(x[p, s], n, 0.5, win, "AVG") for s in range(steps)])
+        own = []
+        for r, eng in enumerate(ranks):
+            lo, hi, nhalo, e_lo, e_hi = eng.scan_shard(steps, r, world)
+            own.append(_own_spectra(ksa, torch, eng, x_dev, passes, steps, lo, hi))
+        ksa.scan_allstitch(ranks, own, steps, passes)
+        want = one.scan_state()
+        got = ksa.scan_gather_state(ranks, steps)
+        for k in CURVES:
+            assert np.array_equal(got[k], want[k]), "%s differs from the single engine (batch %d)" % (k, batch)
+        for r, eng in enumerate(ranks):
+            st = eng.scan_state()
+            assert st["hm_index"] == want["hm_index"] and st["passes"] == want["passes"]
+            assert np.array_equal(st["fftHM"], want["fftHM"]), "ring of engine %d (batch %d)" % (r, batch)
+        if passes <= 5:
+            for k in ("cur", "max", "min", "avg"):
+                assert_db(got["Fft." + k.capitalize()], getattr(ref, k), what="sharded scan vs oracle " + k)
+            assert_db(want["fftHM"][:ref.passes], ref.hm[:ref.passes], what="sharded scan vs oracle hm")
+    for e in ranks + [one]:
+        e.close()
+
+
+def test_band_sharded_fmscan_golden_eight_ranks(ksa, torch_cuda):
+    """BASELINE configs[2] at full size (18 bands of 16384, shares of 2-3 at 8 ranks) through ksa_scan_allstitch
+    against the reference-run golden."""
+    torch = torch_cuda
+    g = golden("scan_fm_n16384")
+    n, full, passes, steps = int(g["fft_size"]), int(g["full"]), int(g["passes"]), int(g["steps"])
+    x = _regen_iq(g, full * steps * passes).reshape(passes, steps, full)
+    x_dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+    world = 8
+    ranks = [_scan_engine(ksa, g, 3 * passes) for _ in range(world)]
+    own = []
+    for r, eng in enumerate(ranks):
+        lo, hi, *_ = eng.scan_shard(steps, r, world)
+        assert 2 <= hi - lo <= 3
+        own.append(_own_spectra(ksa, torch, eng, x_dev, passes, steps, lo, hi))
+    ksa.scan_allstitch(ranks, own, steps, passes)
+    st = ksa.scan_gather_state(ranks, steps)
+    hm = ranks[3].scan_state()
+    st.update(fftHM=hm["fftHM"])
+    assert hm["hm_index"] == int(g["hm_index"])
+    _check_sampled(st, g, "fm 8 ranks")
+    assert_db(hm["fftHM"][:passes], g["hm_rows"][:passes], what="fm 8 ranks waterfall rows")
+    for e in ranks:
+        e.close()
+
+
+def test_scan_stitch_range_refusals(ksa, torch_cuda):
+    torch = torch_cuda
+    n = 64
+    eng = ksa.SpectrumEngine(n, full_size=512, non_overlap=0.5, window="ones", max_frames=8, scan_total_entries=4 * n)
+    db = torch.zeros((1, 4, n), dtype=torch.float32, device="cuda")
+    with pytest.raises(ksa.KsaError, match="at hand"):       # elements from band 2 on need band 1 as a halo
+        eng.scan_stitch_range_dev(db, None, 0, 2, 6, 7, 1, 2 * 32, 4 * n)
+    with pytest.raises(ksa.KsaError, match="outside"):
+        eng.scan_stitch_range_dev(db, None, 0, 2, 9, 7, 1, 64, 128)
+    with pytest.raises(ksa.KsaError, match="pending"):
+        eng.scan_rows()
+    eng.close()
+
+
+# ------------------------------------------------------------------------------- ksa_set_stream ordering
+def test_set_stream_orders_against_the_old_stream(ksa, torch_cuda):
+    """Engine-owned state is written on stream A and read on stream B right after ksa_set_stream: the new stream
+    must wait for the old one (event), whatever the streams' relative speed."""
+    torch = torch_cuda
+    n, full, frames = 4096, 32768, 512
+    x = orc.synth_iq(full * 4, 5).astype(np.complex64).reshape(4, full)
+    dev = torch.view_as_real(torch.from_numpy(x)).cuda().repeat(frames // 4, 1, 1).contiguous()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, max_frames=frames, stream=sa.cuda_stream)
+    ref = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, max_frames=frames)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        eng.set_stream(sa.cuda_stream if rep % 2 == 0 else sb.cuda_stream)
+        eng.frames_dev(dev, ksa.FMT_C64, frames)
+        ref.frames_dev(dev, ksa.FMT_C64, frames)
+    eng.set_stream(sb.cuda_stream if eng is not None else 0)
+    a, b = eng.state(), ref.state()
+    for k in CURVES + ("fftHM",):
+        assert np.array_equal(a[k], b[k]), k
+    eng.close()
+    ref.close()
+
+
+# ------------------------------------------------------------------------------- multi-rank rehearsals on one GPU
+@pytest.mark.parametrize("cfg,gpus,extra,units", [(2, 6, ["--frames", "256"], 256 * 15 * 6), (3, 6, ["--passes", "4"], 4 * 18 * 71),
+                                                  (4, 4, ["--passes", "8"], 8 * 1226 * 71), (3, 2, ["--passes", "130"], 130 * 18 * 71)])
+def test_bench_self_launch_many_ranks_on_one_gpu(cfg, gpus, extra, units):
+    """`python bench.py --gpus N` (the driver's command shape) with N ranks sharing this one GPU over gloo: the
+    launcher, uneven band shares (18 bands over 6 ranks = 3 each; 1226 over 4), the halo exchange, the row
+    all-gather and the JSON contract.  (A one-GPU box admits 6 GPU processes; 8 ranks are rehearsed in-process by
+    test_band_sharded_* / test_allreduce_state_* and on CPU by tests/test_distributed_gloo.py.)"""
+    out = _bench(["--config", str(cfg), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--no-cpu"] + extra,
+                 env={"KSA_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == gpus and out["steps"] == 2
+    assert out["scaling"] == ("weak" if cfg in (2, 5) else "strong")
+    assert abs(out["value"] * out["ms_per_step"] / 1e3 - units) / units < 1e-6
+    assert out["config"]["collective_bytes_per_rank_per_step"] is not None
+
+
+# ------------------------------------------------------------------------------- plot_highs ties (unpinned order)
+def test_device_highs_with_tied_floor_cells(ksa, torch_cuda):
+    """Scan state starts at dB(minAmp4Clip) everywhere (K:603-608), so a curve with few peaks has many tied cells.
+    numpy's argsort (K:251) leaves the order of ties undefined; what is defined -- and checked here against the
+    oracle -- is the number of markers and the SET of marked levels."""
+    n, full, fs = 64, 512, 2.4e6
+    start, end = 100e6, 100e6 + 6 * fs
+    centers = orc.scan_steps(start, end, fs, 0.5)
+    steps = len(centers)
+    ref = orc.ScanState(n, start, end, fs, GAIN, 1e-7, 64)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.1, window="ones", gain=GAIN, min_amp=1e-7, xres=64,
+                             max_frames=steps, scan_total_entries=ref.total)
+    # only bands 2 and 7 carry a tone: everything else sits exactly on the clip floor
+    t = np.arange(full)
+    x = np.zeros((steps, full), dtype=np.complex64)
+    x[2] = (0.5 * np.exp(2j * np.pi * 0.125 * t)).astype(np.complex64)
+    x[7] = (0.25 * np.exp(-2j * np.pi * 0.25 * t)).astype(np.complex64)
+    win = orc.window_table("ones", n)
+    ref.run_pass([orc.curscan(x[s], n, 0.1, win, "AVG") for s in range(steps)])
+    eng.scan_pass(x)
+    cells = ref.total // 4
+    lv = orc.plotcompress(ref.cur, cells, "MAX")
+    freqs = np.linspace(start, end, cells)
+    want = orc.plot_highs(freqs, lv, 0.025, 12)
+    idx, lvl = eng.highs(cells, "MAX", "cur", min_sep=0.025 * (cells - 1), count=12, scan=True)
+    assert len(idx) == len(want)
+    assert_db(np.sort(lvl), np.sort(np.array([w[1] for w in want])), what="marked levels as a set")
+    eng.close()
+
+
+# ------------------------------------------------------------------------------- sample-reuse kernels, full batches
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
+@pytest.mark.parametrize("q,mode", [(0.25, "AVG"), (0.25, "MAX"), (0.25, "MIN"), (0.25, "RAW"), (0.5, "MAX"), (0.5, "MIN")])
+def test_reuse_kernels_on_full_batches(ksa, torch_cuda, n, q, mode):
+    """spectrum_kernel<N, ., RM = 4 | 8, fold> (75 % / 50 % overlap with the carried samples in registers) on batches
+    large enough that the window-split latency mode is off (and, at N = 1024, the two-frames-per-workgroup kernel
+    is on): every fold mode against the oracle, complex64 and uint8."""
+    torch = torch_cuda
+    full = 8 * n
+    distinct, frames = 5, 2048
+    x = orc.synth_iq(full * distinct, 900 + n).astype(np.complex64).reshape(distinct, full)
+    win = orc.window_table("hanning", n)
+    for fmt in ("c64", "u8"):
+        if fmt == "c64":
+            tile = torch.view_as_real(torch.from_numpy(x)).cuda()
+            src = x
+        else:
+            raw = np.stack([orc.quantize_u8(x[i] * 0.8) for i in range(distinct)])
+            tile = torch.from_numpy(raw).cuda()
+            src = np.stack([orc.unpack_u8(raw[i]) for i in range(distinct)])
+        dev = tile.repeat(-(-frames // distinct), *([1] * (tile.dim() - 1)))[:frames].contiguous()
+        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning", cumu_mode=mode, max_frames=frames)
+        out = torch.empty((frames, n), dtype=torch.float32, device="cuda")
+        eng.curscan_dev(dev, ksa.FMT_C64 if fmt == "c64" else ksa.FMT_U8, frames, out)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for i in range(distinct):
+            want = orc.curscan(src[i], n, q, win, mode)
+            assert_lin(got[i], want, what="N=%d q=%s %s %s frame %d" % (n, q, mode, fmt, i))
+            assert np.array_equal(got[i], got[i + distinct * ((frames - 1 - i) // distinct)]), "replicated frame differs"
+        eng.close()

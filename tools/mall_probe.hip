@@ -16,7 +16,7 @@ __global__ void rd(const float4* p, size_t n, float* out) {
 }
 int main() {
   float* out; hipMalloc(&out, 4);
-  size_t sizes_mb[] = {32, 64, 96, 128, 192, 256, 384, 512, 1024, 4096};
+  size_t sizes_mb[] = {8, 16, 32, 64, 96, 128, 160, 192, 224, 256, 384, 512, 1024, 4096};
   for (size_t mb : sizes_mb) {
     size_t bytes = mb << 20, n = bytes / 16;
     float4* buf; if (hipMalloc(&buf, bytes) != hipSuccess) { printf("alloc %zu failed\n", mb); continue; }
