@@ -261,7 +261,7 @@ def test_band_sharded_fmscan_golden_eight_ranks(ksa, torch_cuda):
 def test_scan_stitch_range_refusals(ksa, torch_cuda):
     torch = torch_cuda
     n = 64
-    eng = ksa.SpectrumEngine(n, full_size=512, non_overlap=0.5, window="ones", max_frames=8, scan_total_entries=4 * n)
+    eng = ksa.SpectrumEngine(n, full_size=512, non_overlap=0.5, window="ones", max_frames=8, xres=64, scan_total_entries=4 * n)
     db = torch.zeros((1, 4, n), dtype=torch.float32, device="cuda")
     with pytest.raises(ksa.KsaError, match="at hand"):       # elements from band 2 on need band 1 as a halo
         eng.scan_stitch_range_dev(db, None, 0, 2, 6, 7, 1, 2 * 32, 4 * n)
@@ -297,13 +297,14 @@ def test_set_stream_orders_against_the_old_stream(ksa, torch_cuda):
 
 
 # ------------------------------------------------------------------------------- multi-rank rehearsals on one GPU
-@pytest.mark.parametrize("cfg,gpus,extra,units", [(2, 6, ["--frames", "256"], 256 * 15 * 6), (3, 6, ["--passes", "4"], 4 * 18 * 71),
+@pytest.mark.parametrize("cfg,gpus,extra,units", [(2, 5, ["--frames", "256"], 256 * 15 * 5), (3, 5, ["--passes", "4"], 4 * 18 * 71),
                                                   (4, 4, ["--passes", "8"], 8 * 1226 * 71), (3, 2, ["--passes", "130"], 130 * 18 * 71)])
 def test_bench_self_launch_many_ranks_on_one_gpu(cfg, gpus, extra, units):
     """`python bench.py --gpus N` (the driver's command shape) with N ranks sharing this one GPU over gloo: the
-    launcher, uneven band shares (18 bands over 6 ranks = 3 each; 1226 over 4), the halo exchange, the row
-    all-gather and the JSON contract.  (A one-GPU box admits 6 GPU processes; 8 ranks are rehearsed in-process by
-    test_band_sharded_* / test_allreduce_state_* and on CPU by tests/test_distributed_gloo.py.)"""
+    launcher, uneven band shares (18 bands over 5 ranks = 3 or 4 each; 1226 over 4), the halo exchange, the row
+    all-gather and the JSON contract.  (A one-GPU box admits 6 GPU processes, this test process included: 5 ranks at
+    most; 8 ranks are rehearsed in-process by test_band_sharded_* / test_allreduce_state_* and on CPU by
+    tests/test_distributed_gloo.py.)"""
     out = _bench(["--config", str(cfg), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--no-cpu"] + extra,
                  env={"KSA_BENCH_BACKEND": "gloo"})
     assert out["n_gpus"] == gpus and out["steps"] == 2
