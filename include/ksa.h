@@ -199,7 +199,10 @@ int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, fl
  * (0 cur, 1 max, 2 min, 3 avg; reduced to `cells` groups with `mode` as above) from its highest level down and
  * mark a cell unless an already marked one is closer than min_sep_cells (= pltHighsDelta4Marking * (x[-1]-x[0]) /
  * cell width, K:249-250, K:261-262), until `count` (<= 64) are marked (K:268-269).  As in the reference NaN sorts
- * above +inf and the lowest point is never visited (K:258).  idx_host / lvl_host: [count]; *found = cells marked. */
+ * above +inf and the lowest point is never visited (K:258).  Equal levels are taken higher index first; the reference's
+ * order among equal levels is undefined (numpy's unstable argsort, K:251) and its spacing test runs on float64
+ * frequencies, so tie order and a spacing of exactly min_sep_cells are parity-unpinned.
+ * idx_host / lvl_host: [count]; *found = cells marked. */
 int ksa_read_highs(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, int32_t curve, double min_sep_cells,
                    int32_t count, int32_t* idx_host, float* lvl_host, int32_t* found);
 

@@ -1143,6 +1143,20 @@ static int gather_all(ksa_engine* const* h, int n, size_t nfloats, float* (*bloc
   return 0;
 }
 
+// Direct xGMI copies between the engines' GPUs where the hardware allows them (hipMemcpyPeerAsync works either way,
+// through host staging otherwise).  Best effort: "already enabled" and "not supported" are not errors here.
+static void enable_peer_access(ksa_engine* const* h, int n) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      const int a = h[i]->cfg.device, b = h[j]->cfg.device;
+      if (a == b) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+      if (hipSetDevice(a) == hipSuccess) (void)hipDeviceEnablePeerAccess(b, 0);
+      (void)hipGetLastError();
+    }
+}
+
 static int check_handles(ksa_engine* const* h, int n) {
   if (!h || n < 1) return fail("need at least one engine handle");
   for (int i = 0; i < n; ++i) {
@@ -1153,6 +1167,7 @@ static int check_handles(ksa_engine* const* h, int n) {
         a.scan_hop != b.scan_hop || a.scan_hm_width != b.scan_hm_width)
       return fail("engine %d has a different geometry than engine 0", i);
   }
+  enable_peer_access(h, n);
   return 0;
 }
 

@@ -201,6 +201,13 @@ struct Tune {
 #else
   static constexpr bool WIN_GLOBAL = Plan<N>::T >= 512;
 #endif
+  // N = 64: a transform is held by the four lanes of one DPP quad, so the one exchange between its two passes is a
+  // 4x4 transpose inside the quad (quad_perm moves + selects, no LDS, no barrier).  Measured against the LDS
+  // exchange on MI355X at the quickFullScan shape: see DESIGN.md section 4.1 (-DKSA_QUAD=0/1 for the A/B).
+#ifndef KSA_QUAD
+#define KSA_QUAD 0
+#endif
+  static constexpr bool QUAD_XCHG = KSA_QUAD && N == 64;
   static constexpr int LDS_BYTES = Plan<N>::LDS_BYTES + (WIN_LDS ? N * 4 : 0);
   // Fold mode (AVG/MAX/MIN) as a template constant of the kernel instead of a branch inside the window loop:
   // with the branch, hipcc copies the 16 accumulators to and from the branch's registers in every window (32
@@ -216,6 +223,30 @@ struct Tune {
   static constexpr bool fold_const(int rm) { return !(N == 4096 && rm == 0); }
 #endif
 };
+
+// 4x4 transpose of r[0..3] across the four lanes of a DPP quad: afterwards r[j] of lane q holds what r[q] of lane j
+// held.  Two butterfly stages (lane ^ 1 on register pairs (0,1), (2,3); lane ^ 2 on (0,2), (1,3)); per pair one select
+// of the element to hand over, one quad_perm move and two selects: the wave-local form of a Stockham exchange.
+__device__ __forceinline__ float dpp_quad_xor1(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ float dpp_quad_xor2(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
+}
+__device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2, float& r3, bool odd1, bool odd2) {
+  {
+    const float g = dpp_quad_xor1(odd1 ? r0 : r1);
+    if (odd1) r0 = g; else r1 = g;
+    const float h = dpp_quad_xor1(odd1 ? r2 : r3);
+    if (odd1) r2 = h; else r3 = h;
+  }
+  {
+    const float g = dpp_quad_xor2(odd2 ? r0 : r2);
+    if (odd2) r0 = g; else r2 = g;
+    const float h = dpp_quad_xor2(odd2 ? r1 : r3);
+    if (odd2) r1 = h; else r3 = h;
+  }
+}
 
 // RM > 0: consecutive windows are exactly RM*L samples apart (L = N/16 threads), so thread l's samples
 // l + L*q of window k+1 are its samples q+RM of window k: the raw values stay in VGPRs and only RM new
@@ -368,7 +399,23 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
         dft_first<R0>(v);
       }
       KSA_STAMP(1);
-      if constexpr (M >= 2) {
+      if constexpr (Tune<N>::QUAD_XCHG) {
+        // N = 64 = 4 * 16: butterfly i = l + 4b wrote output t to position 4l + 16b + t, the last pass reads
+        // l' + 4t': register 4b + j of lane l' must hold what register 4b + l' of lane j holds -- a 4x4 transpose
+        // inside the quad for every b, real and imaginary parts alike.  (The lanes of a quad share one slot, so
+        // `active` is uniform over the quad.)
+        static_assert(!Tune<N>::QUAD_XCHG || (L == 4 && R0 == 4 && M == 2), "quad exchange: N = 64 only");
+        const bool odd1 = l & 1, odd2 = l & 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          quad_transpose4(v[4 * b].x, v[4 * b + 1].x, v[4 * b + 2].x, v[4 * b + 3].x, odd1, odd2);
+          quad_transpose4(v[4 * b].y, v[4 * b + 1].y, v[4 * b + 2].y, v[4 * b + 3].y, odd1, odd2);
+        }
+        if (active) {
+          if constexpr (FUSED_LAST) dft16_fused(v, reinterpret_cast<const float2(&)[15]>(twl));
+          else dft16_tw(v, twl[0], twl[1], twl[2], twl[3], twl[4], twl[5]);
+        }
+      } else if constexpr (M >= 2) {
         KSA_SYNC();  // previous round's / frame's LDS reads are done
         KSA_STAMP(2);
         if (active) {

@@ -49,6 +49,11 @@ __host__ __device__ constexpr int pad32(int i) { return i + (i >> 5); }
 #ifndef KSA32_TW6
 #define KSA32_TW6 1        // last pass from 6 twiddles per butterfly (24 VGPRs) instead of 15 folded ones (60 VGPRs)
 #endif
+#ifndef KSA32_TWL_DYN
+#define KSA32_TWL_DYN 0    // last pass, second butterfly: this many of its 6 twiddles are re-read from the L2-resident table per
+                           // window instead of living in VGPRs (2 VGPRs each) -- the explicit form of what the register allocator
+                           // otherwise does with scratch memory (9-13 spilled registers reloaded per window)
+#endif
 #ifndef KSA32_WIN_REGS
 #define KSA32_WIN_REGS 0   // 1: the thread's 32 window taps live in VGPRs (0: re-read from the L2-resident table per window)
 #endif
@@ -93,7 +98,8 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
       // rows of the folded table that are plain powers: c10 = w^1, c20 = w^2, c30 = w^3 (k1 = 0), then w^4, w^8, w^12
       constexpr int rows[6] = {3, 4, 5, 0, 1, 2};
 #pragma unroll
-      for (int e = 0; e < 6; ++e) twl[b][e] = p.tw_last[(b * 15 + rows[e]) * L + l];
+      for (int e = 0; e < 6; ++e)
+        if (!(b == 1 && e >= 6 - KSA32_TWL_DYN)) twl[b][e] = p.tw_last[(b * 15 + rows[e]) * L + l];
     } else {
 #pragma unroll
       for (int e = 0; e < 15; ++e) twl[b][e] = p.tw_last[(b * 15 + e) * L + l];
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
   const int total = p.nframes * NP;
   typedef typename std::conditional<FMT == FMT_C64, u32x2, unsigned short>::type raw_t;
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.window), 0, N * 4, 0x00020000);
+  const auto twrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.tw_last), 0, 30 * L * 8, 0x00020000);
   float win[32];
   auto load_taps = [&]() {
 #pragma unroll
@@ -233,8 +240,20 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
           u[t] = my[pad32(l + L * (b + 2 * t))];
 #endif
         }
-        if constexpr (KSA32_TW6) dft16_tw_at<0>(u, twl[b][0], twl[b][1], twl[b][2], twl[b][3], twl[b][4], twl[b][5]);
-        else dft16_fused_at<0>(u, reinterpret_cast<const float2(&)[15]>(twl[b]));
+        if constexpr (KSA32_TW6) {
+          float2 tb[6];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) {
+            if (b == 1 && e >= 6 - KSA32_TWL_DYN) {
+              constexpr int rows[6] = {3, 4, 5, 0, 1, 2};
+              const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(twrsrc, l * 8, (15 + rows[e]) * L * 8, 0);
+              tb[e] = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
+            } else {
+              tb[e] = twl[b][e];
+            }
+          }
+          dft16_tw_at<0>(u, tb[0], tb[1], tb[2], tb[3], tb[4], tb[5]);
+        } else dft16_fused_at<0>(u, reinterpret_cast<const float2(&)[15]>(twl[b]));
         if (cm == CUMU_AVG) {
 #pragma unroll
           for (int i = 0; i < 16; ++i)

@@ -258,6 +258,32 @@ def test_band_sharded_fmscan_golden_eight_ranks(ksa, torch_cuda):
         e.close()
 
 
+def test_sharded_scan_driver_dummy_band_world1(ksa, torch_cuda):
+    """distributed.ShardedScan on one rank with a failed tune (step_ok): the dummy band of K:637-639 through the
+    driver's own fill, against the oracle."""
+    torch = torch_cuda
+    dmod = importlib.import_module("prgs-sdr-kspecanal_amd.distributed")
+    n, full, fs = 256, 2048, 2.4e6
+    start, end = 100e6, 104.8e6
+    steps, passes = len(orc.scan_steps(start, end, fs, 0.5)), 2
+    x = orc.synth_iq(full * steps * passes, 31).astype(np.complex64).reshape(passes, steps, full)
+    win = orc.window_table("hanning", n)
+    ok = np.ones((passes, steps), dtype=np.uint8)
+    ok[0, 1] = ok[1, 3] = 0
+    ref = orc.ScanState(n, start, end, fs, GAIN, 1e-7, 64)
+    for p in range(passes):
+        ref.run_pass([orc.curscan(x[p, s], n, 0.1, win, "AVG") if ok[p, s] else None for s in range(steps)])
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.1, window="hanning", gain=GAIN, min_amp=1e-7, xres=64,
+                             max_frames=steps * passes, scan_total_entries=ref.total)
+    run = dmod.ShardedScan(eng)
+    run.run_passes(torch.view_as_real(torch.from_numpy(x)).cuda(), ksa.FMT_C64, steps, passes, step_ok=ok)
+    st = run.gather_state(steps)
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], getattr(ref, k), what="driver dummy band " + k)
+    assert_db(st["fftHM"][:passes], ref.hm[:passes], what="driver dummy band hm")
+    eng.close()
+
+
 def test_scan_stitch_range_refusals(ksa, torch_cuda):
     torch = torch_cuda
     n = 64

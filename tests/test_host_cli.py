@@ -145,3 +145,25 @@ def test_c_abi_exports_every_declared_symbol():
     if not torch.cuda.is_available():
         with pytest.raises(pkg.KsaError):
             pkg.SpectrumEngine(512)
+
+
+def test_header_is_plain_c_and_library_exports_match(tmp_path):
+    """include/ksa.h is the drop-in boundary: it must compile as C99 on its own (plain pointers and sizes, no C++ /
+    torch types), and the dynamic symbol table of libksa.so must carry exactly the declared entry points."""
+    import re
+    import subprocess
+    root = os.path.join(os.path.dirname(GOLDEN), "..")
+    hdr = os.path.join(root, "include", "ksa.h")
+    src = tmp_path / "use_ksa.c"
+    names = sorted(set(re.findall(r"\b(ksa_[a-z0-9_]+)\s*\(", open(hdr).read())))
+    src.write_text('#include "ksa.h"\n#include <stddef.h>\n'
+                   'typedef void (*fn_t)(void);\nstatic const fn_t table[] = {' + ", ".join("(fn_t)%s" % n for n in names) + '};\n'
+                   'int use_ksa(void) { ksa_config c; c.abi_version = KSA_ABI_VERSION; return (int)sizeof(table) + c.abi_version + KSA_HM_ROWS; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "use_ksa.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib = os.path.join(root, "prgs-sdr-kspecanal_amd", "libksa.so")
+    nm = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True)
+    assert nm.returncode == 0, nm.stderr
+    exported = {ln.split()[-1] for ln in nm.stdout.splitlines() if " T " in ln and ln.split()[-1].startswith("ksa_")}
+    assert exported == set(names), exported ^ set(names)
