@@ -798,12 +798,29 @@ __global__ __launch_bounds__(256) void scan_stitch_kernel(const StitchParams p) 
     if (covered && !p.base_is_raw) {
       if (ncover <= 2) {
         // straight-line loads (no inner loop): all 2*AHEAD are in flight before the first is used
+        // (running pointers: the distance between passes differs between the own block and the halo block, so it is
+        //  a per-thread value -- one 64-bit add per load instead of a 64-bit multiply.  A whole group of AHEAD passes
+        //  -- every group but the batch's last -- takes the branch-free form.)
         float a[AHEAD], b[AHEAD];
+        if (ps0 + AHEAD <= p.npasses) {
 #pragma unroll
-        for (int u = 0; u < AHEAD; ++u) {
-          const bool in = ps0 + u < p.npasses;
-          a[u] = in ? pa[(ps0 + u) * sa] : 0.f;
-          b[u] = in && ncover == 2 ? pb[(ps0 + u) * sb] : 0.f;
+          for (int u = 0; u < AHEAD; ++u) { a[u] = *pa; pa += sa; }
+          if (ncover == 2) {
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) { b[u] = *pb; pb += sb; }
+          } else {
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) b[u] = 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < AHEAD; ++u) {
+            const bool in = ps0 + u < p.npasses;
+            a[u] = in ? *pa : 0.f;
+            b[u] = in && ncover == 2 ? *pb : 0.f;
+            pa += sa;
+            pb += sb;
+          }
         }
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) nxt[u] = ncover == 2 ? (a[u] + b[u]) * 0.5f : a[u];
