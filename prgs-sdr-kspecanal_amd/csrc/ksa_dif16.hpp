@@ -97,7 +97,14 @@ __global__ __launch_bounds__(256) void dif16_kernel(const DifParams p) {
       ya = cmul(ya, make_float2(wb[b].x, wb[b].y));
       yb = cmul(yb, make_float2(wb[b].z, wb[b].w));
     }
-    *reinterpret_cast<float4*>(z + (long long)k2 * p.nwin * N1) = make_float4(ya.x, ya.y, yb.x, yb.y);
+#ifndef KSA_DIF_NT_STORE
+#define KSA_DIF_NT_STORE 1   // Z is written with the non-temporal policy: it is read once, by the next kernel (+3 % at config 5; 0: A/B)
+#endif
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4* const dst = reinterpret_cast<f32x4*>(z + (long long)k2 * p.nwin * N1);
+    const f32x4 val = {ya.x, ya.y, yb.x, yb.y};
+    if constexpr (KSA_DIF_NT_STORE) __builtin_nontemporal_store(val, dst);
+    else *dst = val;
   }
 }
 

@@ -277,6 +277,55 @@ __device__ __forceinline__ void dft32_fused(float2 (&v)[32], float2 w16, const f
 
 __host__ __device__ constexpr int perm32(int p) { return 2 * (((p & 15) >> 2) | ((p & 3) << 2)) + (p >> 4); }
 
+// ---- first pass with the window multiply folded in ---------------------------------------------------------
+// The first radix-4 level of the first pass works on windowed samples r*w (K:391: tSamples*win).  (r0 w0 +- r2 w2) is
+// one product and two FMAs per component instead of two products and two adds: 16 VALU instructions fewer per
+// thread and window for R0 = 16 / 4 (of ~650 at N = 4096).  v holds the RAW samples, w the matching taps.
+template <int BASE, int STRIDE, int SZ>
+__device__ __forceinline__ void dft4_win(float2 (&v)[SZ], const float (&w)[SZ]) {
+  const float2 a0 = v[BASE], a1 = v[BASE + STRIDE], a2 = v[BASE + 2 * STRIDE], a3 = v[BASE + 3 * STRIDE];
+  const float w0 = w[BASE], w1 = w[BASE + STRIDE], w2 = w[BASE + 2 * STRIDE], w3 = w[BASE + 3 * STRIDE];
+  const float2 t0 = make_float2(a0.x * w0, a0.y * w0), t1 = make_float2(a1.x * w1, a1.y * w1);
+  const float2 s0 = make_float2(fmaf(a2.x, w2, t0.x), fmaf(a2.y, w2, t0.y));
+  const float2 d0 = make_float2(fmaf(-a2.x, w2, t0.x), fmaf(-a2.y, w2, t0.y));
+  const float2 s1 = make_float2(fmaf(a3.x, w3, t1.x), fmaf(a3.y, w3, t1.y));
+  const float2 d1 = make_float2(fmaf(-a3.x, w3, t1.x), fmaf(-a3.y, w3, t1.y));
+  v[BASE] = cadd(s0, s1);
+  v[BASE + 2 * STRIDE] = csub(s0, s1);
+  v[BASE + STRIDE] = make_float2(d0.x + d1.y, d0.y - d1.x);      // d0 - j*d1
+  v[BASE + 3 * STRIDE] = make_float2(d0.x - d1.y, d0.y + d1.x);  // d0 + j*d1
+}
+
+// dft_first<R0> on raw samples and their taps (R0 = 16 or 4); same output positions as dft_first
+template <int R0>
+__device__ __forceinline__ void dft_first_win(float2 (&v)[16], const float (&w)[16]) {
+  static_assert(R0 == 16 || R0 == 4, "windowed first pass: radix 16 or 4");
+  if constexpr (R0 == 16) {
+    dft4_win<0, 4>(v, w);
+    dft4_win<1, 4>(v, w);
+    dft4_win<2, 4>(v, w);
+    dft4_win<3, 4>(v, w);
+    v[5] = mul_w16<1>(v[5]);
+    v[6] = mul_w16<2>(v[6]);
+    v[7] = mul_w16<3>(v[7]);
+    v[9] = mul_w16<2>(v[9]);
+    v[10] = mul_w16<4>(v[10]);
+    v[11] = mul_w16<6>(v[11]);
+    v[13] = mul_w16<3>(v[13]);
+    v[14] = mul_w16<6>(v[14]);
+    v[15] = mul_w16<9>(v[15]);
+    dft4<0, 1>(v);
+    dft4<4, 1>(v);
+    dft4<8, 1>(v);
+    dft4<12, 1>(v);
+  } else {
+    dft4_win<0, 1>(v, w);
+    dft4_win<4, 1>(v, w);
+    dft4_win<8, 1>(v, w);
+    dft4_win<12, 1>(v, w);
+  }
+}
+
 // output index held at register position P after the in-place transforms above
 template <int R>
 __host__ __device__ constexpr int perm(int p) {

@@ -208,6 +208,11 @@ struct Tune {
 #define KSA_QUAD 0
 #endif
   static constexpr bool QUAD_XCHG = KSA_QUAD && N == 64;
+  // window multiply folded into the first radix-4 level of pass 0 (dft_first_win): first-pass radix 16 or 4
+#ifndef KSA_WIN_FUSED
+#define KSA_WIN_FUSED 1
+#endif
+  static constexpr bool WIN_FUSED = KSA_WIN_FUSED && (Plan<N>::R0 == 16 || Plan<N>::R0 == 4);
   static constexpr int LDS_BYTES = Plan<N>::LDS_BYTES + (WIN_LDS ? N * 4 : 0);
   // Fold mode (AVG/MAX/MIN) as a template constant of the kernel instead of a branch inside the window loop:
   // with the branch, hipcc copies the 16 accumulators to and from the branch's registers in every window (32
@@ -355,6 +360,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       const int k = k_lo + (S == 1 ? rd : rd * S + slot);   // wave-uniform when one transform fills the workgroup
       const bool active = S == 1 || k < k_hi;
       float2 v[16];
+      float wpos[16];   // WIN_FUSED: the taps in the register order of v
 #ifndef KSA_PF
 #define KSA_PF 0   // 1 (reuse path only): the RM new samples of window k+1 are requested while window k is transformed
 #endif
@@ -377,15 +383,18 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+          const int pos = (q % B0) * R0 + (q / B0);
+          float2 x;
           if constexpr (FMT == FMT_C64) {
             // (scalar copies first: __builtin_bit_cast on a vector element reads element 0 twice)
             const unsigned xr = raw[q].x, xi = raw[q].y;
-            v[(q % B0) * R0 + (q / B0)] = make_float2(__uint_as_float(xr) * win[q], __uint_as_float(xi) * win[q]);
+            x = make_float2(__uint_as_float(xr), __uint_as_float(xi));
           } else {
-            const unsigned short x = raw[q];   // (b - offset)/scale * w, taps pre-divided by the scale
-            v[(q % B0) * R0 + (q / B0)] = make_float2(((float)(x & 0xff) - p.u8_offset) * win[q],
-                                                      ((float)(x >> 8) - p.u8_offset) * win[q]);
+            const unsigned short b = raw[q];   // (b - offset)/scale * w, taps pre-divided by the scale
+            x = make_float2((float)(b & 0xff) - p.u8_offset, (float)(b >> 8) - p.u8_offset);
           }
+          if constexpr (Tune<N>::WIN_FUSED) { v[pos] = x; wpos[pos] = win[q]; }
+          else v[pos] = make_float2(x.x * win[q], x.y * win[q]);
         }
       }
       if (RM > 0) {
@@ -396,7 +405,8 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       }
       KSA_STAMP(0);
       if (active) {
-        dft_first<R0>(v);
+        if constexpr (Tune<N>::WIN_FUSED) dft_first_win<R0>(v, wpos);
+        else dft_first<R0>(v);
       }
       KSA_STAMP(1);
       if constexpr (Tune<N>::QUAD_XCHG) {

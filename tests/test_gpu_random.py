@@ -59,10 +59,24 @@ def test_random_configuration(ksa, case):
     lin = torch.empty((frames, n), dtype=torch.float32, device="cuda")
     eng.curscan_dev(dev, code, frames, lin)
     assert_lin(lin.cpu().numpy(), lin_ref, what="linear")
-    eng.frames_dev(dev, code, frames)
+    rows_dev = torch.empty((frames, n), dtype=torch.float32, device="cuda")
+    eng.frames_dev(dev, code, frames, cur_db=rows_dev)
     st = eng.state()
     for k in ("cur", "max", "min"):
         assert_db(st["Fft." + k.capitalize()], getattr(st_ref, k), what=k)
+    # Row A10 on EVERY bin, ill-conditioned ones included: the oracle's accumulate (data_cumu, K:470-476) run over the
+    # device's own per-frame dB rows must give the device's Cur / Max / Min exactly and its Avg to float32 rounding --
+    # this separates the accumulate arithmetic from the fp32 transform noise that the comparison below has to allow for.
+    rows = rows_dev.cpu().numpy().astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        ema = rows[0].copy()
+        for f in range(1, frames):
+            ema = (ema + rows[f]) / 2                                  # K:137-139
+    assert np.array_equal(st["Fft.Cur"], rows[-1]) and np.array_equal(st["Fft.Max"], rows.max(axis=0))
+    assert np.array_equal(st["Fft.Min"], rows.min(axis=0))
+    assert np.array_equal(np.isnan(st["Fft.Avg"]), np.isnan(ema)) and np.array_equal(np.isneginf(st["Fft.Avg"]), np.isneginf(ema))
+    fin = np.isfinite(ema)
+    assert np.max(np.abs(st["Fft.Avg"][fin] - ema[fin]), initial=0.0) <= 2e-4 * max(1.0, np.max(np.abs(ema[fin]), initial=0.0)), "avg vs EMA of the device rows"
     # Avg is an EMA of dB values (K:137-139): a frame in which a bin all but cancels (float64 ~1e-16, fp32 ~1e-8 of
     # the strongest bin) moves its average by tens of dB.  Such bins are compared only where every frame's value is
     # within 50 dB of the batch maximum, i.e. well above the fp32 noise floor.
