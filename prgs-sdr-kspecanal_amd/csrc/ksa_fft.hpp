@@ -277,6 +277,25 @@ __device__ __forceinline__ void dft32_fused(float2 (&v)[32], float2 w16, const f
 
 __host__ __device__ constexpr int perm32(int p) { return 2 * (((p & 15) >> 2) | ((p & 3) << 2)) + (p >> 4); }
 
+// Second radix-4 level of an untwiddled radix-16: group k1 takes its inputs times W16^(n2*k1).  (The FMA-fused form
+// with the constants as twiddles -- 24 instead of 28 instructions for groups 1 and 3 -- measured 1 % SLOWER at config 2:
+// longer dependent chains, constants through SGPRs)
+__device__ __forceinline__ void dft16_level_b(float2 (&v)[16]) {
+  v[5] = mul_w16<1>(v[5]);
+  v[6] = mul_w16<2>(v[6]);
+  v[7] = mul_w16<3>(v[7]);
+  v[9] = mul_w16<2>(v[9]);
+  v[10] = mul_w16<4>(v[10]);
+  v[11] = mul_w16<6>(v[11]);
+  v[13] = mul_w16<3>(v[13]);
+  v[14] = mul_w16<6>(v[14]);
+  v[15] = mul_w16<9>(v[15]);
+  dft4<0, 1>(v);
+  dft4<4, 1>(v);
+  dft4<8, 1>(v);
+  dft4<12, 1>(v);
+}
+
 // ---- first pass with the window multiply folded in ---------------------------------------------------------
 // The first radix-4 level of the first pass works on windowed samples r*w (K:391: tSamples*win).  (r0 w0 +- r2 w2) is
 // one product and two FMAs per component instead of two products and two adds: 16 VALU instructions fewer per
@@ -305,19 +324,7 @@ __device__ __forceinline__ void dft_first_win(float2 (&v)[16], const float (&w)[
     dft4_win<1, 4>(v, w);
     dft4_win<2, 4>(v, w);
     dft4_win<3, 4>(v, w);
-    v[5] = mul_w16<1>(v[5]);
-    v[6] = mul_w16<2>(v[6]);
-    v[7] = mul_w16<3>(v[7]);
-    v[9] = mul_w16<2>(v[9]);
-    v[10] = mul_w16<4>(v[10]);
-    v[11] = mul_w16<6>(v[11]);
-    v[13] = mul_w16<3>(v[13]);
-    v[14] = mul_w16<6>(v[14]);
-    v[15] = mul_w16<9>(v[15]);
-    dft4<0, 1>(v);
-    dft4<4, 1>(v);
-    dft4<8, 1>(v);
-    dft4<12, 1>(v);
+    dft16_level_b(v);
   } else {
     dft4_win<0, 1>(v, w);
     dft4_win<4, 1>(v, w);
