@@ -211,6 +211,31 @@ def spawn_ranks(n):
     sys.stdout.flush()
 
 
+def secondary_configs(fmt):
+    """The other BASELINE configurations (C3 fmScan, C4 quickFullScan shape, C5 fftSize 65536 at 75 % overlap) as
+    short runs in child processes after the headline's timed region, so that the record the driver keeps carries a
+    driver-run number for each of them too: {config: {value, unit, ms_per_step, roofline fractions} | {error}}.  The
+    headline's own fields are untouched; `python bench.py --config K` gives the full line of configuration K."""
+    res = {}
+    for k in (3, 4, 5):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(k), "--fmt", fmt, "--steps", "10",
+                                "--warmup", "2", "--no-cpu", "--no-secondary"], capture_output=True, text=True, timeout=240)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                res[str(k)] = {"error": (r.stderr or "no output")[-300:]}
+                continue
+            d = json.loads(line[-1])
+            rf = d["roofline"]
+            res[str(k)] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                           "msamples_per_s": d["msamples_per_s"], "steps": d["steps"], "kernel": rf["kernel"],
+                           "avg_kernel_ms": rf["avg_kernel_ms"], "frac": rf["frac"], "frac_step": rf["frac_step"],
+                           "flop_frac": rf["flop_frac"], "traffic": rf["traffic"]}
+        except Exception as ex:      # a failing side run must never take the headline line with it
+            res[str(k)] = {"error": repr(ex)[:300]}
+    return res
+
+
 def csrc_sha256():
     """Hash of the kernel sources the library is built from: stamps profiles/pmc_traffic.json so that counter
     traffic measured on an older kernel is never reported for a newer one."""
@@ -245,6 +270,8 @@ def main():
     ap.add_argument("--fmt", choices=("c64", "u8"), default="c64")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="length of each of the 5 CPU measurements")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline run on one GPU: skip the short runs of the other BASELINE configurations (3, 4, 5)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1, zeroSpan only: run the multi-GPU merge path on a one-rank group, to price its fixed cost")
     args = ap.parse_args()
@@ -416,6 +443,8 @@ def main():
             multi = cpu_baseline_multicore(args.config, nwin, args.cpu_seconds)
             if multi is not None:
                 out["cpu_baseline_multicore"] = multi
+        if world == 1 and args.config == 2 and not args.no_secondary and not args.force_collective:
+            out["secondary_configs"] = secondary_configs(args.fmt)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -339,6 +339,20 @@ def test_bench_self_launch_many_ranks_on_one_gpu(cfg, gpus, extra, units):
     assert out["config"]["collective_bytes_per_rank_per_step"] is not None
 
 
+def test_bench_headline_line_carries_the_secondary_configs():
+    """The default (driver) form of bench.py: the headline line of config 2 plus a short run of configs 3, 4, 5 each,
+    so that every BASELINE configuration has a driver-run number in the record."""
+    d = _bench(["--frames", "2048", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.3"], timeout=1200)
+    assert d["config"]["baseline_config"] == 2 and d["n_gpus"] == 1
+    sec = d["secondary_configs"]
+    assert sorted(sec) == ["3", "4", "5"]
+    for k, want in (("3", "fmScan"), ("4", "quickFullScan"), ("5", "65536")):
+        assert "error" not in sec[k], sec[k]
+        assert want in sec[k]["workload"] and sec[k]["value"] > 0 and 0 < sec[k]["frac"] < 1 and 0 < sec[k]["flop_frac"] < 1
+    d2 = _bench(["--frames", "2048", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-secondary"])
+    assert "secondary_configs" not in d2
+
+
 # ------------------------------------------------------------------------------- plot_highs ties (unpinned order)
 def test_device_highs_with_tied_floor_cells(ksa, torch_cuda):
     """Scan state starts at dB(minAmp4Clip) everywhere (K:603-608), so a curve with few peaks has many tied cells.
