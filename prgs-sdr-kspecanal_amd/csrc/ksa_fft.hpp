@@ -297,9 +297,10 @@ __device__ __forceinline__ void dft16_level_b(float2 (&v)[16]) {
 }
 
 // ---- first pass with the window multiply folded in ---------------------------------------------------------
-// The first radix-4 level of the first pass works on windowed samples r*w (K:391: tSamples*win).  (r0 w0 +- r2 w2) is
-// one product and two FMAs per component instead of two products and two adds: 16 VALU instructions fewer per
-// thread and window for R0 = 16 / 4 (of ~650 at N = 4096).  v holds the RAW samples, w the matching taps.
+// The first radix-4 level of the first pass works on windowed samples r*w (K:391: tSamples*win): (r0 w0 +- r2 w2) as
+// one product and two FMAs per component.  hipcc's FMA fusion reaches the same instruction count from the separate
+// multiply (PMC: unchanged), but the explicit form schedules better: +1.6 % at config 2.
+// v holds the RAW samples, w the matching taps.
 template <int BASE, int STRIDE, int SZ>
 __device__ __forceinline__ void dft4_win(float2 (&v)[SZ], const float (&w)[SZ]) {
   const float2 a0 = v[BASE], a1 = v[BASE + STRIDE], a2 = v[BASE + 2 * STRIDE], a3 = v[BASE + 3 * STRIDE];

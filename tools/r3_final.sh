@@ -8,10 +8,12 @@ mkdir -p gpurun_out/r3final
 if [ $what = tests ] || [ $what = all ]; then
   timeout -k 10 900 python3 -m pytest tests -m gpu -q > gpurun_out/r3final/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/r3final/pytest.log
   tail -5 gpurun_out/r3final/pytest.log
-  KSA_RANDOM_CASES=300 KSA_RANDOM_SEED=7 timeout -k 10 900 python3 -m pytest tests/test_gpu_random.py -m gpu -q > gpurun_out/r3final/soak.log 2>&1; echo "soak rc $?" >> gpurun_out/r3final/soak.log
+  KSA_RANDOM_CASES=500 KSA_RANDOM_SEED=7 timeout -k 10 900 python3 -m pytest tests/test_gpu_random.py -m gpu -q > gpurun_out/r3final/soak.log 2>&1; echo "soak rc $?" >> gpurun_out/r3final/soak.log
   tail -3 gpurun_out/r3final/soak.log
 fi
 if [ $what = bench ] || [ $what = all ]; then
+  ( time timeout -k 10 900 python3 bench.py > gpurun_out/r3final/bench_default.json 2> gpurun_out/r3final/bench_default.err ) 2> gpurun_out/r3final/bench_default.time
+  grep real gpurun_out/r3final/bench_default.time; cut -c1-300 gpurun_out/r3final/bench_default.json
   for k in 2 3 4 5; do
     timeout -k 10 400 python3 bench.py --config $k > gpurun_out/r3final/bench_c$k.json 2> gpurun_out/r3final/bench_c$k.err || echo "bench c$k failed"
     timeout -k 10 300 python3 bench.py --config $k --fmt u8 --no-cpu > gpurun_out/r3final/bench_c${k}_u8.json 2> gpurun_out/r3final/bench_c${k}_u8.err || echo "bench c$k u8 failed"
