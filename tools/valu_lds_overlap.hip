@@ -1,0 +1,195 @@
+// Do VALU work and LDS traffic overlap on one CU when they come from DIFFERENT workgroups that each alternate between the
+// two (the structure of spectrum_kernel: exchange -> barrier -> butterflies -> barrier -> exchange ...)?
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/vlo tools/valu_lds_overlap.hip && /tmp/vlo
+// Workgroups of 256 threads (4 waves, one per SIMD), W = 1 / 2 / 3 of them per CU (dynamic LDS pads the occupancy).
+// Per "transform" a wave issues V independent-chain v_fma_f32 (VALU phase) and S ds_write_b64 + S ds_read_b64 (LDS
+// phase) separated by workgroup barriers, as the real kernel does.  Modes: VALU only, LDS only, both alternating.
+// If both ~= max(VALU only, LDS only) the two pipes overlap across workgroups; if ~= their sum they do not.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+template <int MODE, int V, int S>
+__global__ __launch_bounds__(256) void probe(float* out, int iters) {
+  extern __shared__ float2 lds[];
+  const int tid = threadIdx.x;
+  float a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = tid * 0.001f + i;
+  float2 r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = make_float2(tid + i, tid - i);
+  const float c0 = 0.999f, c1 = 0.001f;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE != 1) {
+#pragma unroll
+      for (int v = 0; v < V / 16; ++v)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));
+    }
+    if (MODE != 0) {
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < S; ++s) lds[tid * 17 + (s & 15)] = r[s & 15];   // 16 consecutive per thread, padded: conflict free
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < S; ++s) r[s & 15] = lds[tid + 256 * (s & 15) + (s >> 4)];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  float acc = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc += a[i] + r[i].x + r[i].y;
+  if (acc == 12345.678f) out[tid] = acc;
+}
+
+// The real kernel's shape: three VALU blocks of V/3 instructions on CH independent chains, two exchanges of 16 stores |
+// barrier | 16 loads each with a barrier in front (4 barriers per transform), optionally GL streaming global loads of
+// 8 bytes per lane per transform (waited for at the top of the next one) and TR transcendental (v_sqrt) instructions.
+template <int V, int CH, int GL, int TR, int PF = 1, int XL = 0>
+__global__ __launch_bounds__(256) void shaped(float* out, const float2* __restrict__ src, long long nsrc, int iters) {
+  extern __shared__ float2 lds[];
+  const int tid = threadIdx.x;
+  float a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = tid * 0.001f + i;
+  float2 r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = make_float2(tid + i, tid - i);
+  const float c0 = 0.999f, c1 = 0.001f;
+  float2 g[GL > 0 ? GL : 1];
+  const long long mask = nsrc - 1;   // nsrc is a power of two
+  long long pos = ((long long)blockIdx.x * 256 + tid) & mask;
+#define VALU_BLOCK(n)                                                                                        \
+  _Pragma("unroll") for (int v = 0; v < (n); ++v) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[v % CH]) : "v"(c0), "v"(c1))
+  if (GL > 0 && PF == 2) {
+#pragma unroll
+    for (int q = 0; q < GL; ++q) g[q] = src[(pos + (long long)q * 256) & mask];
+    pos = (pos + (long long)gridDim.x * 256 * GL) & mask;
+  }
+  for (int it = 0; it < iters; ++it) {
+    if (GL > 0 && PF != 2) {
+#pragma unroll
+      for (int q = 0; q < GL; ++q) g[q] = src[(pos + (long long)q * 256) & mask];
+      pos = (pos + (long long)gridDim.x * 256 * GL) & mask;
+    }
+    if (GL > 0 && PF != 1) {     // PF 0: the loads are needed at once (window multiply); PF 2: they were issued one transform ago
+#pragma unroll
+      for (int q = 0; q < GL; ++q) a[q % CH] += g[q].x * g[q].y;
+      if (PF == 2) {
+#pragma unroll
+        for (int q = 0; q < GL; ++q) g[q] = src[(pos + (long long)q * 256) & mask];
+        pos = (pos + (long long)gridDim.x * 256 * GL) & mask;
+      }
+    }
+    VALU_BLOCK(V / 3);
+    if (GL > 0 && PF == 1) {
+#pragma unroll
+      for (int q = 0; q < GL; ++q) a[q % CH] += g[q].x * g[q].y;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) lds[tid * 17 + s] = r[s];
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) r[s] = lds[XL ? (tid + (tid >> 4)) + 272 * s + e : tid + 256 * s + e];   // XL: the real kernel's one-in-16 padding (2-way conflict per 32 lanes)
+      if (XL && e == 0) {
+        float2 tw[15];
+#pragma unroll
+        for (int s = 0; s < 15; ++s) tw[s] = lds[4352 + s * 16 + (tid & 15)];          // middle-pass twiddles: 16 distinct addresses per wave
+#pragma unroll
+        for (int s = 0; s < 15; ++s) { a[s % CH] += tw[s].x; a[(s + 1) % CH] += tw[s].y; }
+      }
+      if (XL && e == 1) {
+        const float4* t4 = reinterpret_cast<const float4*>(lds + 4608);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { const float4 w = t4[s * 256 + tid]; a[s % CH] += w.x + w.y + w.z + w.w; }   // window taps
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      VALU_BLOCK(V / 3);
+    }
+#pragma unroll
+    for (int t = 0; t < TR; ++t) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[t % CH]));
+  }
+  float acc = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc += a[i] + r[i].x + r[i].y;
+  if (acc == 12345.678f) out[tid] = acc;
+}
+
+template <int V, int CH, int GL, int TR, int PF = 1, int XL = 0>
+float run_shaped(int wg_per_cu, int iters, float* out, const float2* src, long long nsrc) {
+  const int lds_bytes = wg_per_cu == 1 ? 120 * 1024 : wg_per_cu == 2 ? 72 * 1024 : 48 * 1024;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(shaped<V, CH, GL, TR, PF, XL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int grid = 256 * wg_per_cu;
+  shaped<V, CH, GL, TR, PF, XL><<<grid, 256, lds_bytes>>>(out, src, nsrc, 10);
+  hipEventRecord(e0);
+  shaped<V, CH, GL, TR, PF, XL><<<grid, 256, lds_bytes>>>(out, src, nsrc, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / iters / wg_per_cu;   // us per transform per CU
+}
+
+template <int MODE, int V, int S>
+float run(int wg_per_cu, int iters, float* out) {
+  const int lds_bytes = wg_per_cu == 1 ? 120 * 1024 : wg_per_cu == 2 ? 72 * 1024 : 48 * 1024;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(probe<MODE, V, S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int grid = 256 * wg_per_cu;
+  probe<MODE, V, S><<<grid, 256, lds_bytes>>>(out, 10);
+  hipEventRecord(e0);
+  probe<MODE, V, S><<<grid, 256, lds_bytes>>>(out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms;
+}
+
+int main() {
+  float* out;
+  hipMalloc(&out, 4096);
+  const int iters = 20000;
+  // V = 640 VALU instructions, S = 32 stores + 32 loads of 8 bytes per lane: one 4096-point transform's worth per wave
+  printf("per iteration and workgroup: 640 v_fma per wave, 32 ds_write_b64 + 32 ds_read_b64 per wave; %d iterations\n", iters);
+  for (int w = 1; w <= 3; ++w) {
+    const float tv = run<0, 640, 32>(w, iters, out), tl = run<1, 640, 32>(w, iters, out), tb = run<2, 640, 32>(w, iters, out);
+    // time per "transform" per CU: w workgroups per CU each do `iters`
+    const double k = 1e3 / (double)iters / w;   // us per transform per CU
+    printf("W = %d WG/CU: VALU only %.3f us  LDS only %.3f us  both %.3f us  (sum %.3f, max %.3f) per transform per CU\n", w, tv * k,
+           tl * k, tb * k, (tv + tl) * k, (tv > tl ? tv : tl) * k);
+  }
+  // the same with twice the waves per workgroup-equivalent: 6 workgroups per CU of half the work each is not possible
+  // with 48 KB each; instead 3 WG/CU with half the VALU per wave shows how the balance point moves
+  for (int w = 3; w <= 3; ++w) {
+    const float tv = run<0, 320, 32>(w, iters, out), tl = run<1, 320, 32>(w, iters, out), tb = run<2, 320, 32>(w, iters, out);
+    const double k = 1e3 / (double)iters / w;
+    printf("W = %d, half the VALU: VALU only %.3f  LDS only %.3f  both %.3f  (sum %.3f)\n", w, tv * k, tl * k, tb * k, (tv + tl) * k);
+  }
+  // the real kernel's shape at 3 workgroups per CU: which ingredient costs what
+  float2* src;
+  const long long nsrc = 1ll << 28;   // 2 GiB of float2
+  hipMalloc(&src, nsrc * 8);
+  hipMemset(src, 0, nsrc * 8);
+  const int it2 = 5000;
+  printf("shaped (3 VALU blocks, 2 exchanges, 4 barriers), us per transform per CU at 3 / 2 WG per CU:\n");
+  printf("  642 fma on 16 chains                      : %.3f / %.3f\n", run_shaped<642, 16, 0, 0>(3, it2, out, src, nsrc), run_shaped<642, 16, 0, 0>(2, it2, out, src, nsrc));
+  printf("  642 fma on 8 chains                       : %.3f / %.3f\n", run_shaped<642, 8, 0, 0>(3, it2, out, src, nsrc), run_shaped<642, 8, 0, 0>(2, it2, out, src, nsrc));
+  printf("  642 fma on 4 chains                       : %.3f / %.3f\n", run_shaped<642, 4, 0, 0>(3, it2, out, src, nsrc), run_shaped<642, 4, 0, 0>(2, it2, out, src, nsrc));
+  printf("  642 fma on 2 chains                       : %.3f / %.3f\n", run_shaped<642, 2, 0, 0>(3, it2, out, src, nsrc), run_shaped<642, 2, 0, 0>(2, it2, out, src, nsrc));
+  printf("  630 fma on 16 chains + 16 v_sqrt          : %.3f / %.3f\n", run_shaped<630, 16, 0, 16>(3, it2, out, src, nsrc), run_shaped<630, 16, 0, 16>(2, it2, out, src, nsrc));
+  printf("  642 fma on 16 chains + 8 global loads     : %.3f / %.3f\n", run_shaped<642, 16, 8, 0>(3, it2, out, src, nsrc), run_shaped<642, 16, 8, 0>(2, it2, out, src, nsrc));
+  printf("  630 fma on 8 chains + 16 sqrt + 8 loads   : %.3f / %.3f\n", run_shaped<630, 8, 8, 16>(3, it2, out, src, nsrc), run_shaped<630, 8, 8, 16>(2, it2, out, src, nsrc));
+  printf("  the same, loads needed at once            : %.3f / %.3f\n", run_shaped<630, 8, 8, 16, 0>(3, it2, out, src, nsrc), run_shaped<630, 8, 8, 16, 0>(2, it2, out, src, nsrc));
+  printf("  the same, loads issued one transform ahead: %.3f / %.3f\n", run_shaped<630, 8, 8, 16, 2>(3, it2, out, src, nsrc), run_shaped<630, 8, 8, 16, 2>(2, it2, out, src, nsrc));
+  printf("  8 loads at once + twiddle / tap LDS reads + padded (2-way) exchange reads: %.3f / %.3f\n", run_shaped<600, 8, 8, 16, 0, 1>(3, it2, out, src, nsrc), run_shaped<600, 8, 8, 16, 0, 1>(2, it2, out, src, nsrc));
+  printf("  16 loads needed at once (no reuse)        : %.3f / %.3f\n", run_shaped<630, 8, 16, 16, 0>(3, it2, out, src, nsrc), run_shaped<630, 8, 16, 16, 0>(2, it2, out, src, nsrc));
+  return 0;
+}
