@@ -136,6 +136,84 @@ float run_shaped(int wg_per_cu, int iters, float* out, const float2* src, long l
   return ms * 1e3f / iters / wg_per_cu;   // us per transform per CU
 }
 
+// Design-space explorer: T threads per workgroup, per wave and transform V v_fma on 8 chains, two exchanges of X stores | barrier
+// | X loads (4 barriers), XT twiddle-like b64 reads, XP tap-like b128 reads from LDS, GL streaming 8-byte global loads and GT
+// 16-byte global loads from a small (cache resident) table, NS v_sqrt; lds_bytes sets the workgroups per CU.
+template <int T, int V, int X, int XT, int XP, int GL, int GT, int NS>
+__global__ __launch_bounds__(T) void explore(float* out, const float2* __restrict__ src, long long nsrc, const float4* __restrict__ tab, int iters) {
+  extern __shared__ float2 lds[];
+  const int tid = threadIdx.x;
+  constexpr int CH = 8;
+  float a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = tid * 0.001f + i;
+  float2 r[X];
+#pragma unroll
+  for (int i = 0; i < X; ++i) r[i] = make_float2(tid + i, tid - i);
+  const float c0 = 0.999f, c1 = 0.001f;
+  const long long mask = nsrc - 1;
+  long long pos = ((long long)blockIdx.x * T + tid) & mask;
+  for (int it = 0; it < iters; ++it) {
+    float2 g[GL > 0 ? GL : 1];
+#pragma unroll
+    for (int q = 0; q < GL; ++q) g[q] = src[(pos + (long long)q * T) & mask];
+    pos = (pos + (long long)gridDim.x * T * GL) & mask;
+#pragma unroll
+    for (int q = 0; q < GT; ++q) { const float4 w = tab[q * T + tid]; a[q % CH] += w.x + w.y + w.z + w.w; }
+#pragma unroll
+    for (int q = 0; q < GL; ++q) a[q % CH] += g[q].x * g[q].y;
+    VALU_BLOCK(V / 3);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < X; ++s) lds[tid * (X + 1) + s] = r[s];
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < X; ++s) r[s] = lds[(tid + (tid >> 4)) + (T + T / 16) * s + e];
+      if (e == 0) {
+#pragma unroll
+        for (int s = 0; s < XT; ++s) { const float2 tw = lds[T * (X + 2) + s * 16 + (tid & 15)]; a[s % CH] += tw.x; a[(s + 1) % CH] += tw.y; }
+      } else {
+        const float4* t4 = reinterpret_cast<const float4*>(lds + T * (X + 2) + 256);
+#pragma unroll
+        for (int s = 0; s < XP; ++s) { const float4 w = t4[s * T + tid]; a[s % CH] += w.x + w.y + w.z + w.w; }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      VALU_BLOCK(V / 3);
+    }
+#pragma unroll
+    for (int t = 0; t < NS; ++t) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[t % CH]));
+  }
+  float acc = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc += a[i];
+#pragma unroll
+  for (int i = 0; i < X; ++i) acc += r[i].x + r[i].y;
+  if (acc == 12345.678f) out[tid] = acc;
+}
+
+template <int T, int V, int X, int XT, int XP, int GL, int GT, int NS>
+float run_explore(int lds_kb, int wg_per_cu, int iters, float* out, const float2* src, long long nsrc, const float4* tab, int lds_bytes_exact = 0) {
+  auto k = explore<T, V, X, XT, XP, GL, GT, NS>;
+  const int lb = lds_bytes_exact ? lds_bytes_exact : lds_kb * 1024;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+  int occ = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, T, lb);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int grid = 256 * wg_per_cu;
+  k<<<grid, T, lb>>>(out, src, nsrc, tab, 10);
+  hipEventRecord(e0);
+  k<<<grid, T, lb>>>(out, src, nsrc, tab, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("[occupancy %d WG/CU] ", occ);
+  return ms * 1e3f / iters / wg_per_cu;
+}
+
 template <int MODE, int V, int S>
 float run(int wg_per_cu, int iters, float* out) {
   const int lds_bytes = wg_per_cu == 1 ? 120 * 1024 : wg_per_cu == 2 ? 72 * 1024 : 48 * 1024;
@@ -191,5 +269,21 @@ int main() {
   printf("  the same, loads issued one transform ahead: %.3f / %.3f\n", run_shaped<630, 8, 8, 16, 2>(3, it2, out, src, nsrc), run_shaped<630, 8, 8, 16, 2>(2, it2, out, src, nsrc));
   printf("  8 loads at once + twiddle / tap LDS reads + padded (2-way) exchange reads: %.3f / %.3f\n", run_shaped<600, 8, 8, 16, 0, 1>(3, it2, out, src, nsrc), run_shaped<600, 8, 8, 16, 0, 1>(2, it2, out, src, nsrc));
   printf("  16 loads needed at once (no reuse)        : %.3f / %.3f\n", run_shaped<630, 8, 16, 16, 0>(3, it2, out, src, nsrc), run_shaped<630, 8, 16, 16, 0>(2, it2, out, src, nsrc));
+  float4* tab;
+  hipMalloc(&tab, 64 * 1024);
+  hipMemset(tab, 0, 64 * 1024);
+  printf("explorer (alternative shapes), us per transform per CU -- compare inside one run:\n");
+  printf("  today: 256 thr, 600 fma, 16+16 x2, 15 tw + 4 taps in LDS, 8 loads, 3 WG/CU (51 KB)   : %.3f\n", run_explore<256, 600, 16, 15, 4, 8, 0, 16>(51, 3, it2, out, src, nsrc, tab));
+  printf("  the same, 53 KB = 54272 B of LDS (the occupancy API says 3, the time says 2 WG/CU)     : %.3f\n", run_explore<256, 600, 16, 15, 4, 8, 0, 16>(53, 3, it2, out, src, nsrc, tab));
+  printf("  the same, 56 KB (2 WG/CU)                                                              : %.3f\n", run_explore<256, 600, 16, 15, 4, 8, 0, 16>(56, 3, it2, out, src, nsrc, tab));
+  printf("  taps from L2 (4 x 16 B loads), 38 KB of LDS, 4 WG/CU                                   : %.3f\n", run_explore<256, 600, 16, 15, 0, 8, 4, 16>(38, 4, it2, out, src, nsrc, tab));
+  printf("  the same at 3 WG/CU                                                                    : %.3f\n", run_explore<256, 600, 16, 15, 0, 8, 4, 16>(38, 3, it2, out, src, nsrc, tab));
+  printf("  512 thr (8 points per thread, pair butterflies): 350 fma, 8+8 x2, 8 tw + 2 taps, 4 loads, 3 WG/CU : %.3f\n", run_explore<512, 350, 8, 8, 2, 4, 0, 8>(51, 3, it2, out, src, nsrc, tab));
+  printf("  the same with 380 fma                                                                  : %.3f\n", run_explore<512, 380, 8, 8, 2, 4, 0, 8>(51, 3, it2, out, src, nsrc, tab));
+  printf("  today, no tap reads                                                                    : %.3f\n", run_explore<256, 600, 16, 15, 0, 8, 0, 16>(51, 3, it2, out, src, nsrc, tab));
+  printf("  today, no tap and no twiddle reads                                                     : %.3f\n", run_explore<256, 600, 16, 0, 0, 8, 0, 16>(51, 3, it2, out, src, nsrc, tab));
+  for (int bytes : {52224, 52736, 53120, 53248, 53760, 54272})
+    printf("  today with exactly %d B of LDS: %.3f\n", bytes, run_explore<256, 600, 16, 15, 4, 8, 0, 16>(0, 3, it2, out, src, nsrc, tab, bytes));
+  printf("  today again                                                                            : %.3f\n", run_explore<256, 600, 16, 15, 4, 8, 0, 16>(51, 3, it2, out, src, nsrc, tab));
   return 0;
 }
