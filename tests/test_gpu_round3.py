@@ -414,3 +414,72 @@ def test_reuse_kernels_on_full_batches(ksa, torch_cuda, n, q, mode):
             assert_lin(got[i], want, what="N=%d q=%s %s %s frame %d" % (n, q, mode, fmt, i))
             assert np.array_equal(got[i], got[i + distinct * ((frames - 1 - i) // distinct)]), "replicated frame differs"
         eng.close()
+
+
+# ------------------------------------------------------------------------------- degenerate shapes of the multi-engine calls
+def test_multi_engine_calls_with_one_engine_and_own_streams(ksa, torch_cuda):
+    """n = 1 (a "node" of one GPU) through ksa_allreduce_state / ksa_scan_allstitch equals the plain single-engine
+    calls, also when the engines run on streams of their own (the copies and merges are ordered by events)."""
+    torch = torch_cuda
+    n, full, frames = 512, 4096, 40
+    x = orc.synth_iq(full * frames, 77).astype(np.complex64).reshape(frames, full)
+    dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    mk = lambda st: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hamming", gain=GAIN, xres=64, max_frames=frames,
+                                       stream=st.cuda_stream if st is not None else None)
+    one, solo = mk(None), mk(streams[0])
+    one.frames_dev(dev, ksa.FMT_C64, frames)
+    solo.frames_dev(dev, ksa.FMT_C64, frames, first_index=0, total_frames=frames, commit=False)
+    ksa.allreduce_state([solo], frames, 0)
+    a, b = one.state(), solo.state()
+    assert all(np.array_equal(a[k], b[k]) for k in CURVES + ("fftHM",)) and a["hm_index"] == b["hm_index"]
+    # two engines on two different streams, 20 frames each
+    torch.cuda.synchronize()
+    pair = [mk(streams[1]), mk(streams[2])]
+    for r, eng in enumerate(pair):
+        eng.set_hm_index((r * 20) % 128)
+        eng.frames_dev(dev[r * 20:(r + 1) * 20], ksa.FMT_C64, 20, first_index=r * 20, total_frames=frames, commit=False)
+    ksa.allreduce_state(pair, 20, 0)
+    for eng in pair:
+        st = eng.state()
+        for k in CURVES + ("fftHM",):
+            assert_db(st[k], a[k], what="two streams " + k)
+    for e in [one, solo] + pair:
+        e.close()
+    # scan: one engine through ksa_scan_allstitch == ksa_scan_passes_dev
+    fs, start, end = 2.4e6, 100e6, 104.8e6
+    steps, passes, n = len(orc.scan_steps(start, end, fs, 0.5)), 3, 256
+    full = 2048
+    xs = orc.synth_iq(full * steps * passes, 78).astype(np.complex64).reshape(passes, steps, full)
+    xd = torch.view_as_real(torch.from_numpy(xs)).cuda()
+    mk2 = lambda: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.1, window="hanning", gain=GAIN, min_amp=1e-7, xres=64,
+                                     max_frames=steps * passes, scan_total_entries=2 * n)
+    p, q = mk2(), mk2()
+    p.scan_passes_dev(xd, ksa.FMT_C64, steps, passes)
+    own = torch.empty((passes, steps, n), dtype=torch.float32, device="cuda")
+    q.curscan_dev(xd, ksa.FMT_C64, passes * steps, own, out_mode=ksa.OUT_DB_CLIP)
+    ksa.scan_allstitch([q], [own], steps, passes)
+    sp, sq = p.scan_state(), q.scan_state()
+    assert all(np.array_equal(sp[k], sq[k]) for k in CURVES + ("fftHM",)) and sp["hm_index"] == sq["hm_index"] == passes
+    got = ksa.scan_gather_state([q], steps)
+    assert all(np.array_equal(got[k], sp[k]) for k in CURVES)
+    p.close()
+    q.close()
+
+
+def test_pinned_buffer_round_trip(ksa):
+    """ksa_host_alloc / ksa_host_free: page-locked capture blocks (complex64) through the host-pointer zeroSpan call."""
+    n, full = 1024, 8192
+    buf = ksa.PinnedBuffer((full,), np.complex64)
+    x = orc.synth_iq(full, 5).astype(np.complex64)
+    buf.array[:] = x
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning")
+    got = eng.curscan(buf.array)
+    assert_lin(got, orc.curscan(x, n, 0.5, orc.window_table("hanning", n)), what="curscan from pinned memory")
+    eng.frame(buf.array)
+    assert eng.state()["frames"] == 1
+    buf.close()
+    buf.close()          # idempotent
+    with pytest.raises(ksa.KsaError):
+        ksa.PinnedBuffer((0,), np.uint8)
+    eng.close()
