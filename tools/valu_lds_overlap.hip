@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters) {
 // The real kernel's shape: three VALU blocks of V/3 instructions on CH independent chains, two exchanges of 16 stores |
 // barrier | 16 loads each with a barrier in front (4 barriers per transform), optionally GL streaming global loads of
 // 8 bytes per lane per transform (waited for at the top of the next one) and TR transcendental (v_sqrt) instructions.
-template <int V, int CH, int GL, int TR, int PF = 1, int XL = 0>
+template <int V, int CH, int GL, int TR, int PF = 1, int XL = 0, int NB = 4>
 __global__ __launch_bounds__(256) void shaped(float* out, const float2* __restrict__ src, long long nsrc, int iters) {
   extern __shared__ float2 lds[];
   const int tid = threadIdx.x;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void shaped(float* out, const float2* __restri
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      __syncthreads();
+      if (NB == 4 || (NB == 3 && e == 0)) __syncthreads();   // NB 3: the second exchange is in place (no barrier in front of its stores); NB 2: neither
 #pragma unroll
       for (int s = 0; s < 16; ++s) lds[tid * 17 + s] = r[s];
       __syncthreads();
@@ -119,16 +119,16 @@ __global__ __launch_bounds__(256) void shaped(float* out, const float2* __restri
   if (acc == 12345.678f) out[tid] = acc;
 }
 
-template <int V, int CH, int GL, int TR, int PF = 1, int XL = 0>
+template <int V, int CH, int GL, int TR, int PF = 1, int XL = 0, int NB = 4>
 float run_shaped(int wg_per_cu, int iters, float* out, const float2* src, long long nsrc) {
   const int lds_bytes = wg_per_cu == 1 ? 120 * 1024 : wg_per_cu == 2 ? 72 * 1024 : 48 * 1024;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(shaped<V, CH, GL, TR, PF, XL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(shaped<V, CH, GL, TR, PF, XL, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   const int grid = 256 * wg_per_cu;
-  shaped<V, CH, GL, TR, PF, XL><<<grid, 256, lds_bytes>>>(out, src, nsrc, 10);
+  shaped<V, CH, GL, TR, PF, XL, NB><<<grid, 256, lds_bytes>>>(out, src, nsrc, 10);
   hipEventRecord(e0);
-  shaped<V, CH, GL, TR, PF, XL><<<grid, 256, lds_bytes>>>(out, src, nsrc, iters);
+  shaped<V, CH, GL, TR, PF, XL, NB><<<grid, 256, lds_bytes>>>(out, src, nsrc, iters);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -268,6 +268,9 @@ int main() {
   printf("  the same, loads needed at once            : %.3f / %.3f\n", run_shaped<630, 8, 8, 16, 0>(3, it2, out, src, nsrc), run_shaped<630, 8, 8, 16, 0>(2, it2, out, src, nsrc));
   printf("  the same, loads issued one transform ahead: %.3f / %.3f\n", run_shaped<630, 8, 8, 16, 2>(3, it2, out, src, nsrc), run_shaped<630, 8, 8, 16, 2>(2, it2, out, src, nsrc));
   printf("  8 loads at once + twiddle / tap LDS reads + padded (2-way) exchange reads: %.3f / %.3f\n", run_shaped<600, 8, 8, 16, 0, 1>(3, it2, out, src, nsrc), run_shaped<600, 8, 8, 16, 0, 1>(2, it2, out, src, nsrc));
+  printf("  ... with 3 barriers per transform (second exchange in place)             : %.3f / %.3f\n", run_shaped<600, 8, 8, 16, 0, 1, 3>(3, it2, out, src, nsrc), run_shaped<600, 8, 8, 16, 0, 1, 3>(2, it2, out, src, nsrc));
+  printf("  ... with 2 barriers per transform (not realisable in 53 KB; for scale)   : %.3f / %.3f\n", run_shaped<600, 8, 8, 16, 0, 1, 2>(3, it2, out, src, nsrc), run_shaped<600, 8, 8, 16, 0, 1, 2>(2, it2, out, src, nsrc));
+  printf("  ... 4 barriers again                                                     : %.3f / %.3f\n", run_shaped<600, 8, 8, 16, 0, 1, 4>(3, it2, out, src, nsrc), run_shaped<600, 8, 8, 16, 0, 1, 4>(2, it2, out, src, nsrc));
   printf("  16 loads needed at once (no reuse)        : %.3f / %.3f\n", run_shaped<630, 8, 16, 16, 0>(3, it2, out, src, nsrc), run_shaped<630, 8, 16, 16, 0>(2, it2, out, src, nsrc));
   float4* tab;
   hipMalloc(&tab, 64 * 1024);
