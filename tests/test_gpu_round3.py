@@ -483,3 +483,21 @@ def test_pinned_buffer_round_trip(ksa):
     with pytest.raises(ksa.KsaError):
         ksa.PinnedBuffer((0,), np.uint8)
     eng.close()
+
+
+def test_plain_c_client(tmp_path):
+    """The boundary is a C ABI: tests/c_client/ksa_client.c (C99, no Python / torch / HIP headers) is compiled with gcc
+    against include/ksa.h + libksa.so and run here -- curscan, the zeroSpan frame loop, a host-pointer scan pass with a
+    dummy band and the device-side Levels, checked inside the program against the closed-form on-bin-tone answers."""
+    exe = str(tmp_path / "ksa_client")
+    pkg = os.path.join(ROOT, "prgs-sdr-kspecanal_amd")
+    rocm = "/opt/rocm/lib"
+    r = subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c_client", "ksa_client.c"), "-o", exe, "-L", pkg, "-lksa", "-lm",
+                        "-Wl,-rpath," + pkg, "-Wl,-rpath," + rocm, "-Wl,-rpath-link," + rocm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c client ok" in r.stdout
