@@ -159,14 +159,16 @@ int ksa_scan_stitch_passes_dev(ksa_engine* e, const float* step_db_dev /* [npass
                                int32_t nsteps, int32_t npasses);
 /* Band-sharded scan (SURVEY 8e "freq-band"): this engine owns the tuned bands [step_lo, step_hi) of every pass and
  * the elements [elem_lo, elem_hi) of the stitched range (normally [step_lo*hop, step_hi*hop), the last rank up to
- * totalEntries).  own_db_dev = [npasses][step_hi-step_lo][N] dB spectra of its bands; halo_db_dev =
+ * totalEntries).  own_db_dev = [npasses][step_hi-step_lo][N] dB spectra of its bands (own_band_major != 0:
+ * [step_hi-step_lo][npasses][N], what one strided ksa_curscan_dev launch per band produces -- it lets a driver transform
+ * the bands its neighbours wait for first and send them while the others are still being transformed); halo_db_dev =
  * [npasses][nhalo][N] spectra of the nhalo bands in front of step_lo that still cover owned elements (the overlap
  * K:645-650 averages: nhalo = ceil(N/hop) - 1 bands, 1 at the usual hop of N/2), received from the left neighbour.
  * Runs exactly the updates of K:643-668 on the owned elements only, and writes this engine's PARTIAL waterfall rows
  * (cell maxima over the owned elements, -inf where it owns none of a cell; K:696-697) for the batch's last
  * min(npasses,128) passes to rows_dev [rows][scan_hm_width] (engine scratch, see ksa_scan_rows_dev). */
-int ksa_scan_stitch_range_dev(ksa_engine* e, const float* own_db_dev, const float* halo_db_dev, int32_t nhalo,
-                              int32_t step_lo, int32_t step_hi, int32_t nsteps, int32_t npasses,
+int ksa_scan_stitch_range_dev(ksa_engine* e, const float* own_db_dev, int32_t own_band_major, const float* halo_db_dev,
+                              int32_t nhalo, int32_t step_lo, int32_t step_hi, int32_t nsteps, int32_t npasses,
                               int32_t elem_lo, int32_t elem_hi);
 /* The partial rows of the last ksa_scan_stitch_range_dev: float[rows][scan_hm_width] on the device. */
 int ksa_scan_rows_dev(ksa_engine* e, float** rows_dev, int32_t* rows);

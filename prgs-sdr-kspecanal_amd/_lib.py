@@ -66,7 +66,7 @@ SIGNATURES = {
     "ksa_scan_stitch_dev": (C.c_int, [_P, _P, _I32]),
     "ksa_scan_passes_dev": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "ksa_scan_stitch_passes_dev": (C.c_int, [_P, _P, _I32, _I32]),
-    "ksa_scan_stitch_range_dev": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "ksa_scan_stitch_range_dev": (C.c_int, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "ksa_scan_rows_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I32)]),
     "ksa_scan_merge_rows_dev": (C.c_int, [_P, _P, _I32, _I32, _I32]),
     "ksa_scan_allstitch": (C.c_int, [C.POINTER(_P), _I32, C.POINTER(_P), _I32, _I32]),

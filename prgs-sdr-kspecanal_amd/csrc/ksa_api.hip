@@ -987,7 +987,7 @@ int ksa_set_hm_index(ksa_engine* e, int32_t hm_index) {
 // ranged == true: partial rows into d_scan_rows for ksa_scan_merge_rows_dev.
 static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int npasses, bool ranged = false,
                        const float* halo_db_dev = nullptr, int nhalo = 0, int step_lo = 0, int step_hi = -1,
-                       int elem_lo = 0, int elem_hi = -1) {
+                       int elem_lo = 0, int elem_hi = -1, int own_band_major = 0) {
   if (!e || !step_db_dev) return fail("null argument");
   const ksa_config& c = e->cfg;
   if (!c.scan_total_entries) return fail("engine was created without scan geometry");
@@ -1005,6 +1005,7 @@ static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int 
   s.step_lo = step_lo;
   s.own_steps = step_hi - step_lo;
   s.nhalo = nhalo;
+  s.own_band_major = own_band_major;
   s.e_lo = elem_lo;
   s.e_hi = elem_hi;
   s.state = e->d_scan_state;
@@ -1053,9 +1054,9 @@ static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int 
 // Bands in front of step_lo that still cover elements from step_lo*hop on: ceil(N/hop) - 1, at most step_lo.
 static int halo_bands(const ksa_config& c, int step_lo) { return std::min(step_lo, (c.fft_size + c.scan_hop - 1) / c.scan_hop - 1); }
 
-int ksa_scan_stitch_range_dev(ksa_engine* e, const float* own_db_dev, const float* halo_db_dev, int32_t nhalo,
-                              int32_t step_lo, int32_t step_hi, int32_t nsteps, int32_t npasses, int32_t elem_lo,
-                              int32_t elem_hi) {
+int ksa_scan_stitch_range_dev(ksa_engine* e, const float* own_db_dev, int32_t own_band_major, const float* halo_db_dev,
+                              int32_t nhalo, int32_t step_lo, int32_t step_hi, int32_t nsteps, int32_t npasses,
+                              int32_t elem_lo, int32_t elem_hi) {
   if (!e) return fail("null engine");
   const ksa_config& c = e->cfg;
   if (!c.scan_total_entries) return fail("engine was created without scan geometry");
@@ -1075,7 +1076,7 @@ int ksa_scan_stitch_range_dev(ksa_engine* e, const float* own_db_dev, const floa
     if (nhalo > 0 && !halo_db_dev) return fail("null halo_db_dev");
   }
   const float* own = own_db_dev ? own_db_dev : e->d_scan_state;   // (an engine that owns no band reads nothing)
-  return scan_stitch(e, own, nsteps, npasses, true, halo_db_dev, nhalo, step_lo, step_hi, elem_lo, elem_hi);
+  return scan_stitch(e, own, nsteps, npasses, true, halo_db_dev, nhalo, step_lo, step_hi, elem_lo, elem_hi, own_band_major != 0);
 }
 
 int ksa_scan_rows_dev(ksa_engine* e, float** rows_dev, int32_t* rows) {
@@ -1230,7 +1231,7 @@ int ksa_scan_allstitch(ksa_engine* const* handles, int32_t n, float* const* own_
                    s->cfg.device, band * 4, e->stream)) return 1;
     }
     const int elem_lo = lo * c.scan_hop, elem_hi = r == n - 1 ? c.scan_total_entries : std::min(c.scan_total_entries, hi * c.scan_hop);
-    if (ksa_scan_stitch_range_dev(e, own_db_dev[r], e->d_scan_halo, nhalo, lo, hi, nsteps, npasses, std::min(elem_lo, elem_hi), elem_hi)) return 1;
+    if (ksa_scan_stitch_range_dev(e, own_db_dev[r], 0, e->d_scan_halo, nhalo, lo, hi, nsteps, npasses, std::min(elem_lo, elem_hi), elem_hi)) return 1;
   }
   // 3. partial waterfall rows: all-to-all copies, merged on every engine
   const int rows = std::min(npasses, KSA_HM_ROWS);

@@ -750,6 +750,7 @@ struct StitchParams {
   const float* halo_db;  // [nhalo][npasses][N] (band major): bands [step_lo - nhalo, step_lo), or null
   int n, nsteps, hop, total;
   int step_lo, own_steps, nhalo;   // single engine: 0, nsteps, 0
+  int own_band_major;              // the own block is [own_steps][npasses][N] (one strided spectrum launch per band) instead of [npasses][own_steps][N]
   int e_lo, e_hi;                  // elements of the stitched range this launch owns (single engine: 0, total)
   float* state;          // [4][total] : cur, max, min, avg
   int first_pass;        // the first pass of this call is pass 0 of the run: it seeds Avg by copy (K:615-618)
@@ -777,6 +778,10 @@ __global__ __launch_bounds__(256) void scan_stitch_kernel(const StitchParams p) 
   // spectrum of band i in pass 0 and the distance between passes (own block or halo block)
   auto band = [&](int i, long long& pass_stride) -> const float* {
     if (i >= p.step_lo) {
+      if (p.own_band_major) {
+        pass_stride = p.n;
+        return p.step_db + (long long)(i - p.step_lo) * p.npasses * p.n;
+      }
       pass_stride = (long long)p.own_steps * p.n;
       return p.step_db + (long long)(i - p.step_lo) * p.n;
     }

@@ -163,30 +163,36 @@ def _follow_current_stream(eng):
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
 
 
-def _p2p(ops_send, ops_recv, group=None):
-    """Post every receive and send of one exchange at once and wait for all of them.  ops_*: [(tensor, peer)].
-    NCCL (= RCCL) moves device tensors directly; gloo (CPU rehearsals, several ranks on one GPU) goes through host
-    copies of device tensors."""
-    if not ops_send and not ops_recv:
-        return
-    if dist.get_backend(group) == "nccl":
-        ops = [dist.P2POp(dist.irecv, t, peer, group) for t, peer in ops_recv]
-        ops += [dist.P2POp(dist.isend, t, peer, group) for t, peer in ops_send]
-        for r in dist.batch_isend_irecv(ops):     # one ncclGroupStart/End: no ordering between the pairs
+class _P2P:
+    """One halo exchange in flight: every receive and send is posted at construction, finish() waits for all of them.
+    ops_*: [(tensor, peer)].  NCCL (= RCCL) moves device tensors directly and asynchronously (one ncclGroupStart/End:
+    the transfers run on RCCL's stream behind the work already queued on the current stream, kernels launched afterwards
+    overlap them; finish() makes the current stream wait); gloo (CPU rehearsals, several ranks on one GPU) goes through
+    host copies of device tensors."""
+
+    def __init__(self, ops_send, ops_recv, group=None):
+        self.staged, self.reqs = [], []
+        if not ops_send and not ops_recv:
+            return
+        if dist.get_backend(group) == "nccl":
+            ops = [dist.P2POp(dist.irecv, t, peer, group) for t, peer in ops_recv]
+            ops += [dist.P2POp(dist.isend, t, peer, group) for t, peer in ops_send]
+            self.reqs = dist.batch_isend_irecv(ops)
+            return
+        for t, peer in ops_recv:
+            buf = torch.empty(t.shape, dtype=t.dtype) if t.is_cuda else t
+            self.staged.append((t, buf))
+            self.reqs.append(dist.irecv(buf, src=peer, group=group))
+        for t, peer in ops_send:
+            self.reqs.append(dist.isend(t.cpu() if t.is_cuda else t, dst=peer, group=group))
+
+    def finish(self):
+        for r in self.reqs:
             r.wait()
-        return
-    staged, reqs = [], []
-    for t, peer in ops_recv:
-        buf = torch.empty(t.shape, dtype=t.dtype) if t.is_cuda else t
-        staged.append((t, buf))
-        reqs.append(dist.irecv(buf, src=peer, group=group))
-    for t, peer in ops_send:
-        reqs.append(dist.isend(t.cpu() if t.is_cuda else t, dst=peer, group=group))
-    for r in reqs:
-        r.wait()
-    for t, buf in staged:
-        if buf is not t:
-            t.copy_(buf)
+        for t, buf in self.staged:
+            if buf is not t:
+                t.copy_(buf)
+        self.reqs, self.staged = [], []
 
 
 class ShardedScan:
@@ -197,12 +203,16 @@ class ShardedScan:
     32 KiB at fmScan), stitches and accumulates its own elements only (ksa_scan_stitch_range_dev), and ONE all-gather of
     the partial waterfall rows ([min(passes,128)][W] floats per rank) completes the ring on every rank
     (ksa_scan_merge_rows_dev).  The curves stay sharded until someone reads them (gather_state).  Buffers are
-    allocated once per (nsteps, npasses)."""
+    allocated once per (nsteps, npasses).  With few bands per rank (<= BAND_MAJOR_MAX: fmScan at 8 ranks has 2-3) every band
+    is its own strided spectrum launch and the bands a neighbour waits for are transformed first, so that the halo travels
+    while the remaining bands are transformed (RCCL send/recv run asynchronously beside the engine's stream)."""
 
     def __init__(self, engine, rank=0, world=1, group=None, device=None):
         self.eng, self.rank, self.world, self.group = engine, rank, world, group
         self.device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
         self._key = None
+
+    BAND_MAJOR_MAX = 8     # up to this many own bands: one strided spectrum launch per band, boundary bands first
 
     def _setup(self, nsteps, npasses):
         eng = self.eng
@@ -210,11 +220,16 @@ class ShardedScan:
         self.lo, self.hi, self.nhalo, self.e_lo, self.e_hi = eng.scan_shard(nsteps, self.rank, self.world)
         mine, n = self.hi - self.lo, eng.fft_size
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.own = torch.empty((npasses, max(mine, 1), n), **f32)
+        # few bands per rank (fmScan at 8 ranks: 2-3): the own block is band major, every band is one strided launch over the
+        # passes, the bands a neighbour waits for go first and travel while the others are transformed.  Many bands per rank
+        # (quickFullScan: 153): one launch over everything, pass major; the halo is a sliver of it.
+        self.band_major = self.world > 1 and 0 < mine <= self.BAND_MAJOR_MAX
+        self.own = torch.empty((max(mine, 1), npasses, n) if self.band_major else (npasses, max(mine, 1), n), **f32)
         self.halo = torch.zeros((max(self.nhalo, 1), npasses, n), **f32)          # band major
         plan = halo_plan(nsteps, self.world, n, eng.scan_hop)[self.rank]
         self.recv = [(src, j, c0, torch.empty((npasses, n - c0), **f32)) for src, j, c0 in plan["recv"]]
         self.send = [(dst, j, c0, torch.empty((npasses, n - c0), **f32)) for dst, j, c0 in plan["send"]]
+        self.send_bands = sorted({j for _, j, _, _ in self.send})
         self.rows = min(npasses, HM_ROWS)
         self.rows_all = torch.empty((self.world, self.rows * eng.scan_hm_width), **f32)
         self.halo_bytes_in = sum(t.numel() * 4 for *_, t in self.recv)
@@ -240,23 +255,48 @@ class ShardedScan:
         mine, n = self.hi - self.lo, eng.fft_size
         if self.world > 1:
             _follow_current_stream(eng)
-        if mine > 0:
-            eng.curscan_dev(iq_local, fmt, npasses * mine, self.own, out_mode=OUT_DB_CLIP)
-            if step_ok is not None:
-                bad = torch.as_tensor(np.asarray(step_ok).reshape(npasses, mine) == 0, device=self.own.device)
-                if bool(bad.any()):
-                    self.own[:, :mine][bad] = float(10.0 * np.log10(max(1.0, eng.min_amp)) - eng.gain)
+        dummy = float(10.0 * np.log10(max(1.0, eng.min_amp)) - eng.gain)          # ones -> Clip2MinAmp -> LogNoGain, K:637-641
+        bad = None
+        if step_ok is not None and mine > 0:
+            bad = torch.as_tensor(np.asarray(step_ok).reshape(npasses, mine) == 0, device=self.own.device)
+            bad = bad if bool(bad.any()) else None
         if self.world == 1:
+            if mine > 0:
+                eng.curscan_dev(iq_local, fmt, npasses * mine, self.own, out_mode=OUT_DB_CLIP)
+                if bad is not None:
+                    self.own[:, :mine][bad] = dummy
             eng.scan_stitch_dev(self.own, nsteps, npasses)
             return
-        # halo: the overlap columns of the bands in front of my first one, straight from their owners
-        for _, j, c0, buf in self.send:
-            buf.copy_(self.own[:, j - self.lo, c0:])
-        _p2p([(buf, dst) for dst, _, _, buf in self.send], [(buf, src) for src, _, _, buf in self.recv], self.group)
+
+        def post_halo():
+            for _, j, c0, buf in self.send:
+                buf.copy_(self.own[j - self.lo, :, c0:] if self.band_major else self.own[:, j - self.lo, c0:])
+            return _P2P([(buf, dst) for dst, _, _, buf in self.send], [(buf, src) for src, _, _, buf in self.recv], self.group)
+
+        if self.band_major:
+            blocks = iq_local.reshape(npasses, mine, -1)
+            first = [b for b in range(mine) if self.lo + b in self.send_bands]
+            rest = [b for b in range(mine) if self.lo + b not in self.send_bands]
+            xchg = None
+            for b in first + rest:
+                if xchg is None and b in rest:
+                    xchg = post_halo()                 # everything a neighbour waits for is queued: it travels under the rest
+                eng.curscan_dev(blocks[:, b], fmt, npasses, self.own[b], out_mode=OUT_DB_CLIP, frame_stride=mine * eng.full_size)
+                if bad is not None and bool(bad[:, b].any()):
+                    self.own[b][bad[:, b]] = dummy
+            if xchg is None:
+                xchg = post_halo()
+        else:
+            if mine > 0:
+                eng.curscan_dev(iq_local, fmt, npasses * mine, self.own, out_mode=OUT_DB_CLIP)
+                if bad is not None:
+                    self.own[:, :mine][bad] = dummy
+            xchg = post_halo()
+        xchg.finish()
         for _, j, c0, buf in self.recv:
             self.halo[j - (self.lo - self.nhalo), :, c0:] = buf
         eng.scan_stitch_range_dev(self.own if mine > 0 else None, self.halo if self.nhalo > 0 else None, self.nhalo,
-                                  self.lo, self.hi, nsteps, npasses, self.e_lo, self.e_hi)
+                                  self.lo, self.hi, nsteps, npasses, self.e_lo, self.e_hi, own_band_major=self.band_major)
         rows = torch.as_tensor(eng.scan_rows(), device=self.device).reshape(-1)
         all_gather_flat(self.rows_all, rows, self.group)
         eng.scan_merge_rows(self.rows_all, self.world, self.rows, npasses)

@@ -301,9 +301,10 @@ class SpectrumEngine:
         nhalo = min(lo, -(-self.fft_size // self.scan_hop) - 1)
         return lo, hi, nhalo, e_lo, e_hi
 
-    def scan_stitch_range_dev(self, own_db, halo_db, nhalo, step_lo, step_hi, nsteps, npasses, elem_lo, elem_hi):
-        check(lib.ksa_scan_stitch_range_dev(self._h, _ptr(own_db), _ptr(halo_db), int(nhalo), int(step_lo), int(step_hi),
-                                            int(nsteps), int(npasses), int(elem_lo), int(elem_hi)))
+    def scan_stitch_range_dev(self, own_db, halo_db, nhalo, step_lo, step_hi, nsteps, npasses, elem_lo, elem_hi,
+                              own_band_major=False):
+        check(lib.ksa_scan_stitch_range_dev(self._h, _ptr(own_db), int(bool(own_band_major)), _ptr(halo_db), int(nhalo),
+                                            int(step_lo), int(step_hi), int(nsteps), int(npasses), int(elem_lo), int(elem_hi)))
 
     def scan_rows(self):
         """Device view float32[rows, W] of the partial waterfall rows of the last scan_stitch_range_dev."""

@@ -141,18 +141,18 @@ class FakeScanEngine:
     def set_stream(self, s):
         pass
 
-    def curscan_dev(self, iq, fmt, nframes, out, out_mode=None):
+    def curscan_dev(self, iq, fmt, nframes, out, out_mode=None, frame_stride=None):
         x = iq.numpy().reshape(nframes, self.full_size, 2)
         o = out.view(-1, self.fft_size)
         for f in range(nframes):
             lin = orc.curscan(x[f, :, 0] + 1j * x[f, :, 1], self.fft_size, self.q_win, self.win, "AVG")
             o[f] = torch.from_numpy(orc.log_no_gain(orc.clip2minamp(lin, self.min_amp), self.gain, inf_to=0).astype(np.float32))
 
-    def scan_stitch_range_dev(self, own, halo, nhalo, lo, hi, nsteps, npasses, e_lo, e_hi):
+    def scan_stitch_range_dev(self, own, halo, nhalo, lo, hi, nsteps, npasses, e_lo, e_hi, own_band_major=False):
         n, hop, tot = self.fft_size, self.scan_hop, self.scan_total
         own = None if own is None else own.numpy().astype(np.float64)
         halo = None if halo is None else halo.numpy().astype(np.float64)
-        band = lambda ps, i: own[ps, i - lo] if i >= lo else halo[i - (lo - nhalo), ps]
+        band = lambda ps, i: (own[i - lo, ps] if own_band_major else own[ps, i - lo]) if i >= lo else halo[i - (lo - nhalo), ps]
         rows = min(npasses, 128)
         self._rows = np.full((rows, self.scan_hm_width), -np.inf)
         g = tot // self.scan_hm_width

@@ -501,3 +501,76 @@ def test_plain_c_client(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "c client ok" in r.stdout
+
+
+# ------------------------------------------------------------------------------- the torch.distributed scan driver on real engines
+def _sharded_scan_rank(rank, world, port, n, sq, passes, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p_ in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    import ksa_oracle as orc_
+    ksa = importlib.import_module("prgs-sdr-kspecanal_amd")
+    dmod = importlib.import_module("prgs-sdr-kspecanal_amd.distributed")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    full, fs, start = 8 * n, 2.4e6, 100e6
+    end = start + 5 * fs
+    steps = len(orc_.scan_steps(start, end, fs, sq))
+    total = 5 * n
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=1e-7, xres=64,
+                             max_frames=max(1, passes * (-(-steps // world))), scan_total_entries=total, scan_non_overlap=sq)
+    run = dmod.ShardedScan(eng, rank, world)
+    lo, hi = dmod.step_range(steps, rank, world)
+    for batch in range(2):
+        x = orc_.synth_iq(full * steps * passes, 300 + batch).astype(np.complex64).reshape(passes, steps, full)
+        ok = np.ones((passes, steps), dtype=np.uint8)
+        ok[0, steps // 2] = 0                                    # a failed tune somewhere in the first pass of each batch
+        mine = np.ascontiguousarray(x[:, lo:hi])
+        dev = torch.view_as_real(torch.from_numpy(mine)).cuda() if hi > lo else torch.empty((0, full, 2), device="cuda")
+        run.run_passes(dev, ksa.FMT_C64, steps, passes, step_ok=ok[:, lo:hi])
+    st = run.gather_state(steps)
+    np.savez(out_path % rank, band_major=int(run.band_major), hm_index=st["hm_index"],
+             **{k: st[k] for k in CURVES + ("fftHM",)})
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+@pytest.mark.parametrize("n,sq,passes,world", [(256, 0.5, 3, 3), (64, 0.125, 2, 3), (256, 0.5, 130, 2)])
+def test_sharded_scan_driver_three_ranks_on_one_gpu(ksa, torch_cuda, tmp_path, n, sq, passes, world):
+    """distributed.ShardedScan with real engines: `world` processes share this GPU over gloo.  (256, 0.5): 10 bands over 3
+    ranks = 3-4 each -> the band-major path (one strided launch per band, boundary band first, halo in flight under the
+    rest); (64, 0.125): 40 bands -> the pass-major path with a 7-band halo; 130 passes: the waterfall ring wraps.  After
+    two batches with a failed tune each, every rank's gathered state equals ONE engine's, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    torch = torch_cuda
+    full, fs, start = 8 * n, 2.4e6, 100e6
+    end = start + 5 * fs
+    steps = len(orc.scan_steps(start, end, fs, sq))
+    one = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=1e-7, xres=64,
+                             max_frames=steps * passes, scan_total_entries=5 * n, scan_non_overlap=sq)
+    for batch in range(2):
+        x = orc.synth_iq(full * steps * passes, 300 + batch).astype(np.complex64).reshape(passes, steps, full)
+        ok = np.ones((passes, steps), dtype=np.uint8)
+        ok[0, steps // 2] = 0
+        one.scan_passes_dev(torch.view_as_real(torch.from_numpy(x)).cuda(), ksa.FMT_C64, steps, passes, step_ok=ok.reshape(-1))
+    want = one.scan_state()
+    one.close()
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_sharded_scan_rank, args=(world, port, n, sq, passes, out), nprocs=world, join=True)
+    majors = []
+    for r in range(world):
+        got = np.load(out % r)
+        majors.append(int(got["band_major"]))
+        assert int(got["hm_index"]) == want["hm_index"]
+        for k in CURVES + ("fftHM",):
+            assert np.array_equal(got[k], want[k]), "%s on rank %d" % (k, r)
+    assert majors == [1 if -(-steps // world) <= 8 else 0] * world          # which path every rank took
