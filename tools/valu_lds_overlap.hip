@@ -139,7 +139,7 @@ float run_shaped(int wg_per_cu, int iters, float* out, const float2* src, long l
 // Design-space explorer: T threads per workgroup, per wave and transform V v_fma on 8 chains, two exchanges of X stores | barrier
 // | X loads (4 barriers), XT twiddle-like b64 reads, XP tap-like b128 reads from LDS, GL streaming 8-byte global loads and GT
 // 16-byte global loads from a small (cache resident) table, NS v_sqrt; lds_bytes sets the workgroups per CU.
-template <int T, int V, int X, int XT, int XP, int GL, int GT, int NS>
+template <int T, int V, int X, int XT, int XP, int GL, int GT, int NS, int NE = 2, int STG = 0>
 __global__ __launch_bounds__(T) void explore(float* out, const float2* __restrict__ src, long long nsrc, const float4* __restrict__ tab, int iters) {
   extern __shared__ float2 lds[];
   const int tid = threadIdx.x;
@@ -160,27 +160,41 @@ __global__ __launch_bounds__(T) void explore(float* out, const float2* __restric
     pos = (pos + (long long)gridDim.x * T * GL) & mask;
 #pragma unroll
     for (int q = 0; q < GT; ++q) { const float4 w = tab[q * T + tid]; a[q % CH] += w.x + w.y + w.z + w.w; }
+    if (STG) {
+      // staged samples: the wave's GL loads cover the span of all its windows once; they go to LDS (aliasing the exchange
+      // buffer) and every thread picks its 16 samples from there: slot s = tid / 4 starts 6.4 samples after slot s - 1
 #pragma unroll
-    for (int q = 0; q < GL; ++q) a[q % CH] += g[q].x * g[q].y;
-    VALU_BLOCK(V / 3);
+      for (int q = 0; q < GL; ++q) lds[q * 64 + (tid & 63)] = g[q];
+      const int off = (int)((tid >> 2) * 6.4f) + (tid & 3);
+      float2 x[16];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+      for (int q = 0; q < 16; ++q) x[q] = lds[off + 4 * q];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a[q % CH] += x[q].x * x[q].y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < GL; ++q) a[q % CH] += g[q].x * g[q].y;
+    }
+    VALU_BLOCK(V / (NE + 1));
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
       __syncthreads();
 #pragma unroll
       for (int s = 0; s < X; ++s) lds[tid * (X + 1) + s] = r[s];
       __syncthreads();
 #pragma unroll
       for (int s = 0; s < X; ++s) r[s] = lds[(tid + (tid >> 4)) + (T + T / 16) * s + e];
-      if (e == 0) {
+      if (e == 0 && XT > 0) {
 #pragma unroll
         for (int s = 0; s < XT; ++s) { const float2 tw = lds[T * (X + 2) + s * 16 + (tid & 15)]; a[s % CH] += tw.x; a[(s + 1) % CH] += tw.y; }
-      } else {
+      }
+      if (e == NE - 1) {
         const float4* t4 = reinterpret_cast<const float4*>(lds + T * (X + 2) + 256);
 #pragma unroll
         for (int s = 0; s < XP; ++s) { const float4 w = t4[s * T + tid]; a[s % CH] += w.x + w.y + w.z + w.w; }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      VALU_BLOCK(V / 3);
+      VALU_BLOCK(V / (NE + 1));
     }
 #pragma unroll
     for (int t = 0; t < NS; ++t) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[t % CH]));
@@ -193,9 +207,9 @@ __global__ __launch_bounds__(T) void explore(float* out, const float2* __restric
   if (acc == 12345.678f) out[tid] = acc;
 }
 
-template <int T, int V, int X, int XT, int XP, int GL, int GT, int NS>
+template <int T, int V, int X, int XT, int XP, int GL, int GT, int NS, int NE = 2, int STG = 0>
 float run_explore(int lds_kb, int wg_per_cu, int iters, float* out, const float2* src, long long nsrc, const float4* tab, int lds_bytes_exact = 0) {
-  auto k = explore<T, V, X, XT, XP, GL, GT, NS>;
+  auto k = explore<T, V, X, XT, XP, GL, GT, NS, NE, STG>;
   const int lb = lds_bytes_exact ? lds_bytes_exact : lds_kb * 1024;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
   int occ = 0;
@@ -287,6 +301,13 @@ int main() {
   printf("  today, no tap and no twiddle reads                                                     : %.3f\n", run_explore<256, 600, 16, 0, 0, 8, 0, 16>(51, 3, it2, out, src, nsrc, tab));
   for (int bytes : {52224, 52736, 53120, 53248, 53760, 54272})
     printf("  today with exactly %d B of LDS: %.3f\n", bytes, run_explore<256, 600, 16, 15, 4, 8, 0, 16>(0, 3, it2, out, src, nsrc, tab, bytes));
+  // the N = 64 kernel's shape (config 4): single-wave workgroups, 16 per CU, one exchange, 16 loads (90 %% overlap: all 16 samples re-read)
+  printf("  N = 64 shape: 64 thr, 350 fma, 16+16 x1, 4 taps, 16 loads, 16 WG/CU (9 KB): %.4f us per wave-round per CU (real kernel: 0.232)\n", run_explore<64, 350, 16, 0, 4, 16, 0, 16, 1>(9, 16, it2 * 4, out, src, nsrc, tab));
+  printf("  the same with 8 loads : %.4f\n", run_explore<64, 350, 16, 0, 4, 8, 0, 16, 1>(9, 16, it2 * 4, out, src, nsrc, tab));
+  printf("  the same with 0 loads : %.4f\n", run_explore<64, 350, 16, 0, 4, 0, 0, 16, 1>(9, 16, it2 * 4, out, src, nsrc, tab));
+  printf("  16 loads, no LDS exchange (X = 0 is not expressible: 1 store + 1 load): %.4f\n", run_explore<64, 350, 1, 0, 4, 16, 0, 16, 1>(9, 16, it2 * 4, out, src, nsrc, tab));
+  printf("  staged: 3 loads -> LDS -> 16 ds_read_b64 per thread (334 fma)               : %.4f\n", run_explore<64, 334, 16, 0, 4, 3, 0, 16, 1, 1>(9, 16, it2 * 4, out, src, nsrc, tab));
+  printf("  16 loads, 12 WG/CU     : %.4f\n", run_explore<64, 350, 16, 0, 4, 16, 0, 16, 1>(12, 12, it2 * 4, out, src, nsrc, tab));
   printf("  today again                                                                            : %.3f\n", run_explore<256, 600, 16, 15, 4, 8, 0, 16>(51, 3, it2, out, src, nsrc, tab));
   return 0;
 }
