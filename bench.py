@@ -426,6 +426,8 @@ def main():
                             "collective_bytes_per_rank_per_step": coll_bytes}, **batch),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": ("counter bytes per step (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes stored in "
+                                          "profiles/pmc_traffic.json for this exact kernel source (sha256-checked); NOT measured by this run") if traffic else None,
                          # counter traffic (L2 <-> fabric; Infinity-Cache hits included) per step over the stage's time
                          "traffic_gbs": (traffic / avg_kernel_s / 1e9) if traffic else None,
                          "traffic_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
