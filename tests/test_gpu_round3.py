@@ -574,3 +574,26 @@ def test_sharded_scan_driver_three_ranks_on_one_gpu(ksa, torch_cuda, tmp_path, n
         for k in CURVES + ("fftHM",):
             assert np.array_equal(got[k], want[k]), "%s on rank %d" % (k, r)
     assert majors == [1 if -(-steps // world) <= 8 else 0] * world          # which path every rank took
+
+
+# ------------------------------------------------------------------------------- row A0: the unpack convention is a parameter
+@pytest.mark.parametrize("n,q", [(512, 0.5), (4096, 0.5), (8192, 0.5), (32768, 0.5)])
+def test_uint8_unpack_with_the_in_tree_legacy_convention(ksa, n, q):
+    """default (b - 127.5) / 127.5 (pyrtlsdr, parity unpinned), offset and scale as parameters.  The one
+    convention the reference tree itself holds is the legacy analyser's (b - 127) / 128 (python/kspecanal.old.py:126-135):
+    the engine configured with u8_offset = 127, u8_scale = 128 must match the oracle's restatement of that arithmetic on
+    every transform path (16-point plan, reuse kernel, 32-point plan, radix-16 first stage)."""
+    full = 4 * n
+    x = orc.synth_iq(full, 4000 + n) * 0.7
+    raw = orc.quantize_u8(x)
+    win = orc.window_table("hanning", n)
+    want = orc.curscan(orc.unpack_u8(raw, offset=127.0, scale=128.0), n, q, win, "AVG")
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning", u8_offset=127.0, u8_scale=128.0)
+    assert_lin(eng.curscan(raw), want, what="legacy unpack N=%d" % n)
+    # and it differs from the default convention by more than the tolerance (the parameter is live)
+    dflt = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning")
+    other = dflt.curscan(raw)
+    assert np.max(np.abs(other - want)) / np.max(want) > 1e-4
+    assert_lin(other, orc.curscan(orc.unpack_u8(raw), n, q, win, "AVG"), what="default unpack N=%d" % n)
+    eng.close()
+    dflt.close()
