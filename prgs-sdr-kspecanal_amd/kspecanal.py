@@ -369,6 +369,16 @@ def data_plotcompress(d, x, y, mode=None):
     return _plotcompress(d, x, "AVG"), _plotcompress(d, y, mode)
 
 
+def data_2d_plotcompress(d, data, mode=None):
+    """K:224-237: every row of a 2-D set reduced like _data_plotcompress (the reference uses it once, to build the scan's
+    initial waterfall buffer at K:614; the engine's rings are born decimated, so this is the host-side name for callers
+    that hold full-width rows)."""
+    mode = d["pltCompressHM"] if mode is None else mode
+    if mode == "RAW":
+        return data
+    return np.array([_plotcompress(d, np.asarray(data)[r, :], mode) for r in range(np.asarray(data).shape[0])])
+
+
 def plot_highs(d, freqs, levels, eng=None, curve=None, scan=False):
     """K:243-272: the strongest points of the last plotted curve, at least pltHighsDelta4Marking of the span apart.
     With an engine the selection runs on the device over the same decimated curve (ksa_read_highs) and only the

@@ -167,3 +167,20 @@ def test_header_is_plain_c_and_library_exports_match(tmp_path):
     assert nm.returncode == 0, nm.stderr
     exported = {ln.split()[-1] for ln in nm.stdout.splitlines() if " T " in ln and ln.split()[-1].startswith("ksa_")}
     assert exported == set(names), exported ^ set(names)
+
+
+def test_data_2d_plotcompress_rows():
+    """K:224-237: row-wise _data_plotcompress; the scan's initial waterfall buffer (K:613-614) is its only use in the reference."""
+    load_pkg()
+    k = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.kspecanal")
+    import ksa_oracle as orc
+    d = {"xRes": 8, "pltCompressHM": "MAX"}
+    rng = np.random.default_rng(3)
+    data = rng.standard_normal((5, 64))
+    got = k.data_2d_plotcompress(d, data)
+    want = np.array([orc.plotcompress(data[r], 8, "MAX") for r in range(5)])
+    assert got.shape == (5, 8) and np.array_equal(got, want)
+    assert np.array_equal(k.data_2d_plotcompress(d, data, "AVG"), np.array([orc.plotcompress(data[r], 8, "AVG") for r in range(5)]))
+    assert k.data_2d_plotcompress(d, data, "RAW") is data
+    hm = np.ones((128, 64)) * 3.9e-8                      # K:613: ones * minAmp4Clip
+    assert np.array_equal(k.data_2d_plotcompress(d, hm), np.full((128, 8), 3.9e-8))
