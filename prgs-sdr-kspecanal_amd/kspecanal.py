@@ -29,7 +29,12 @@ PRGMODES = ("ZEROSPAN", "ZEROSPANSAVE", "ZEROSPANPLAY", "SCAN", "FMSCAN", "QUICK
 PLTCOMPRESS = ("MAX", "MIN", "AVG", "RAW", "CONV")
 
 # key -> (dict name, parser); the reference's spelling is matched case-insensitively (K:815)
-_bool = lambda v: v.upper() == "TRUE"          # K:771-775
+def _arg_boolean(v):
+    """K:771-775."""
+    return v.upper() == "TRUE"
+
+
+_bool = _arg_boolean
 _KEYS = {
     "CENTERFREQ": ("centerFreq", float), "STARTFREQ": ("startFreq", float), "ENDFREQ": ("endFreq", float),
     "SAMPLINGRATE": ("samplingRate", float), "GAIN": ("gain", float), "MINAMP4CLIP": ("minAmp4Clip", float),
@@ -165,34 +170,50 @@ def open_source(d):
     return rtlsdr.RtlSdr()
 
 
-def sdr_setup(d, fC, fS, gain):
-    """K:287-308: tune, discard 16Ki settle samples; on any failure reopen the source and report False."""
-    sdr = d["sdr"]
+_reopen_source = None     # set by main(): how a failed source is re-opened (the reference calls rtlsdr.RtlSdr() again, K:305)
+
+
+def _calc_startendfreq(centerFreq, samplingRate):
+    """K:275-278."""
+    return centerFreq - samplingRate / 2, centerFreq + samplingRate / 2
+
+
+def sdr_info(sdr):
+    """K:281-284 (sources without these attributes print what they have)."""
+    print("INFO:Sdr:SupportedGains:", getattr(sdr, "valid_gains_db", None))
+    print("INFO:Sdr:Bandwidth:", getattr(sdr, "bandwidth", None))
+    print("INFO:Sdr:freqCorrection:", getattr(sdr, "freq_correction", None))
+
+
+def sdr_setup(sdr, fC, fS, gain):
+    """K:287-308, same signature: tune, discard 16Ki settle samples; on any failure close and re-open the source and
+    report False.  Returns (sdr, bOk)."""
     try:
         sdr.sample_rate = fS
         sdr.center_freq = fC
         sdr.gain = gain
+        bOk = True
         sdr.read_samples(16 * 1024)
-        ok = True
     except Exception:
         print("WARN:SetupSDR:FAILED: fC[{}] fS[{}] gain[{}]".format(fC, fS, gain))
         try:
             sdr.close()
         except Exception:
             pass
-        d["sdr"] = open_source(d)
-        ok = False
-    return ok
+        if _reopen_source is not None:
+            sdr = _reopen_source()
+        bOk = False
+    print("SetupSDR:{}: fC[{}] fS[{}] gain[{}]".format(bOk, fC, fS, gain))
+    return sdr, bOk
 
 
 SDR_READ_UNIT = 2 ** 18   # K:311
 
 
-def sdr_read(d, length):
-    """One capture block in <= 2^18-sample reads (K:312-347).  Returns complex64, or uint8 I,Q pairs when
-    iqFormat is u8 and the source can deliver raw bytes (the unpack then runs on the GPU)."""
-    sdr = d["sdr"]
-    raw = d.get("iqFormat") == "u8" and hasattr(sdr, "read_bytes")
+def sdr_read(sdr, length, raw=False):
+    """K:312-347, same signature (+ raw): one capture block in <= 2^18-sample reads.  Returns complex64, or -- raw=True and a
+    source that can deliver bytes -- uint8 I,Q pairs (the unpack then runs on the GPU)."""
+    raw = raw and hasattr(sdr, "read_bytes")
     parts, left = [], int(length)
     while left > 0:
         n = min(left, SDR_READ_UNIT)
@@ -250,7 +271,7 @@ def psd_crosscheck(d, samples, mag):
 
 def sdr_curscan(d):
     """Drop-in for K:351-397: float64[fftSize] linear magnitudes, fftshifted."""
-    samples = sdr_read(d, d["fullSize"])
+    samples = sdr_read(d["sdr"], d["fullSize"], raw=d.get("iqFormat") == "u8")
     mag = get_engine(d).curscan(samples)
     if d["bUsePSD"]:
         psd_crosscheck(d, samples, mag)
@@ -357,6 +378,9 @@ def _plotcompress(d, data, mode):
     if mode == "MIN":        # unreachable in the reference (K:188 vs K:196); implemented as documented there
         return t.min(axis=1)
     return np.average(t, axis=1)
+
+
+_data_plotcompress = _plotcompress     # the reference's name (K:168-202)
 
 
 def data_plotcompress(d, x, y, mode=None):
@@ -470,7 +494,7 @@ def zero_span(d):
         d[k] = None
     d["timeWasStr"] = None
     if d.get("sdr") is not None:
-        sdr_setup(d, d["centerFreq"], d["samplingRate"], d["gain"])
+        d["sdr"], _ = sdr_setup(d["sdr"], d["centerFreq"], d["samplingRate"], d["gain"])
     freqs = np.fft.fftshift(np.fft.fftfreq(d["fftSize"], 1 / d["samplingRate"]) + d["centerFreq"])   # K:444-445
     d["freqs"] = freqs
     print("ZeroSpan: min[{}] max[{}]".format(min(freqs), max(freqs)))
@@ -484,7 +508,7 @@ def zero_span(d):
         eng.set_flags(d["bDataMax"], d["bDataMin"], d["bDataAvg"])          # GUI toggles K:471-476
         if sdr_curscan is _gpu_curscan and not d["bUsePSD"]:
             try:
-                eng.frame(sdr_read(d, d["fullSize"]))                       # fused K:464-484
+                eng.frame(sdr_read(d["sdr"], d["fullSize"], raw=d.get("iqFormat") == "u8"))   # fused K:464-484
             except EOFError:
                 prg_quit(d, "WARN:zero_span: source exhausted, stoping...", False)
         else:
@@ -516,7 +540,7 @@ def zero_span_save(d):
     with open(d["zeroSpanSaveFile"], "wb+") as f:
         for k in ("centerFreq", "samplingRate", "gain"):
             pickle.dump(d[k], f)
-        sdr_setup(d, d["centerFreq"], d["samplingRate"], d["gain"])
+        d["sdr"], _ = sdr_setup(d["sdr"], d["centerFreq"], d["samplingRate"], d["gain"])
         prev = time.time()
         for i in range(d["prgLoopCnt"]):
             if d["cmd.stop"]:
@@ -537,8 +561,7 @@ def zero_span_play_setup(d):
     global sdr_curscan
     d["zeroSpanFile"] = f = open(d["zeroSpanPlayFile"], "rb")
     d["centerFreq"], d["samplingRate"], d["gain"] = _load(f), _load(f), _load(f)
-    d["startFreq"] = d["centerFreq"] - d["samplingRate"] / 2
-    d["endFreq"] = d["centerFreq"] + d["samplingRate"] / 2
+    d["startFreq"], d["endFreq"] = _calc_startendfreq(d["centerFreq"], d["samplingRate"])
     sdr_curscan = zero_span_play
 
 
@@ -600,11 +623,12 @@ def scan_range(d):
         prev = now
         ok = np.ones(steps, dtype=np.uint8)
         for s, fc in enumerate(centers):
-            if not sdr_setup(d, fc, d["samplingRate"], d["gain"]):
+            d["sdr"], bOk = sdr_setup(d["sdr"], fc, d["samplingRate"], d["gain"])
+            if not bOk:
                 print("WARN:_scanRange: Dummy data for {} to {}".format(fc - d["samplingRate"] / 2, fc + d["samplingRate"] / 2))
                 ok[s] = 0                                                   # K:637-639
                 continue
-            blocks[s] = sdr_read(d, d["fullSize"])
+            blocks[s] = sdr_read(d["sdr"], d["fullSize"], raw=u8)
         eng.set_flags(d["bDataMax"], d["bDataMin"], True)
         eng.scan_pass(blocks, step_ok=ok)
         st = eng.scan_state()
@@ -631,16 +655,32 @@ def do_run(d):
         zero_span(d)
 
 
+gD = None     # the reference's module-level state dict (K:1139); handle_sigint needs it
+
+
+def handle_sigint(signum, stack):
+    """K:1118-1119."""
+    prg_quit(gD, "INFO:sigint: quiting on user request...")
+
+
+def handle_signals(d):
+    """K:1122-1123."""
+    signal.signal(signal.SIGINT, handle_sigint)
+
+
 def main(argv=None):
-    global sdr_curscan
+    global sdr_curscan, gD, _reopen_source
     sdr_curscan = _gpu_curscan
-    d = {"cmd.stop": False}
+    d = gD = {"cmd.stop": False}
     handle_args(d, argv)
     _load_siglvls(d)
     print_info(d)
-    signal.signal(signal.SIGINT, lambda *_: prg_quit(d, "INFO:sigint: quiting on user request..."))   # K:1118-1123
+    handle_signals(d)
+    _reopen_source = lambda: open_source(d)
     plt_figures(d)
     d["sdr"] = None if d["prgMode"] == "ZEROSPANPLAY" else open_source(d)   # playback needs no SDR (appendix B)
+    if d["sdr"] is not None:
+        sdr_info(d["sdr"])                                                   # K:1147
     try:
         do_run(d)
     finally:
