@@ -21,3 +21,29 @@ for n, q in ((4096, 0.5), (16384, 0.1), (64, 0.1), (65536, 0.25)):
         dt = (time.perf_counter() - t0) / reps
         print("N=%-6d q=%-4s %-12s %8.1f us/block  %7.1f MS/s  (%d windows)" % (n, q, name, dt * 1e6, full / dt / 1e6, eng.num_windows))
     eng.close()
+
+# scan passes from host memory (ksa_scan_pass_c64 / _u8): one pass per call, pageable and page-locked capture blocks
+for name, n, q, start, end, win in (("fmScan", 16384, 0.1, 88e6, 108e6, "kaiser"), ("quickFullScan", 64, 0.1, 30e6, 1.5e9, "ones")):
+    fs = 2.4e6
+    end, _ = orc.fixup_scan_range(start, end, fs)
+    steps = len(orc.scan_steps(start, end, fs, 0.5))
+    total = int((end - start) / fs) * n
+    full = orc.full_size(n, fs)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=win, xres=min(n, 512), max_frames=steps, scan_total_entries=total)
+    x = np.tile(orc.synth_iq(full * 4, 2).astype(np.complex64).reshape(4, full), (steps // 4 + 1, 1))[:steps].copy()
+    pinned = ksa.PinnedBuffer((steps, full), np.complex64)
+    pinned.array[:] = x
+    raw = np.stack([orc.quantize_u8(x[s] * 0.8) for s in range(min(steps, 4))])
+    raw = np.tile(raw, (steps // 4 + 1, 1))[:steps].copy()
+    for label, arg in (("c64 pageable", x), ("c64 pinned", pinned.array), ("u8 pageable", raw)):
+        for _ in range(3):
+            eng.scan_pass(arg)
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.scan_pass(arg)
+        dt = (time.perf_counter() - t0) / reps
+        print("%-13s %-13s %8.1f us/pass  (%d bands of %d samples: %.1f MS/s, %.2f GB/s over PCIe)" %
+              (name, label, dt * 1e6, steps, full, steps * full / dt / 1e6, arg.nbytes / dt / 1e9))
+    pinned.close()
+    eng.close()
