@@ -8,7 +8,7 @@
   2  zeroSpan, fftSize 4096, 50 % overlap, hanning, complex64 synthetic IQ      (headline, default)
   3  fmScan 88-108 MHz, fftSize 16384 kaiser, 18 steps x 71 windows per pass, stitch + Max/Min/Avg + waterfall
   4  quickFullScan shape (30e6-1.5e9, fftSize 64, 1226 steps per pass), band shard + RCCL gather of the spectra
-  5  zeroSpan, fftSize 65536, 75 % overlap (four-step path), time-chunk shard + RCCL merge of Max/Min/Avg
+  5  zeroSpan, fftSize 65536, 75 % overlap (radix-16 first stage + 4096-point kernel), time-chunk shard + RCCL merge of Max/Min/Avg
 
 One "step" = one pass of the whole hot path over one HBM-resident batch per GPU: `--frames` capture blocks
 (zeroSpan: IQ -> window -> FFT -> |X| -> fold -> dB -> Cur/Max/Min/Avg + waterfall rows) or `--passes` whole scan
@@ -403,9 +403,7 @@ def main():
         achieved = alg_bytes / avg_kernel_s / 1e9
         tflops = units_per_step * nwin * algorithmic_flops_per_fft(n) / avg_kernel_s / 1e12
         step_s = dt / args.steps
-        if info["path"] == 1:
-            kernel = "ksa::fourstep_cols + ksa::fourstep_rows (N = N1*N2 through HBM scratch)"
-        elif info["path"] == 2:
+        if info["path"] == 2:
             kernel = "ksa::dif16_kernel<%s> + ksa::spectrum_kernel<%d,c64> + ksa::dif16_finish_kernel (N = 16*%d)" % (args.fmt, n // 16, n // 16)
         elif info["path"] == 4:
             kernel = "ksa::spectrum_pair_kernel<%d,%s> (two frames per workgroup, packed fp32)" % (n, args.fmt)

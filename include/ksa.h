@@ -220,9 +220,9 @@ int ksa_prof_read(ksa_engine* e, double* spectrum_ms, int64_t* launches);
 /* Resources of the spectrum kernel chosen for this engine (for DESIGN.md / bench.py). */
 int ksa_kernel_info(ksa_engine* e, int32_t* threads, int32_t* lds_bytes, int32_t* vgprs,
                     int32_t* grid, int32_t* path /* 0 = single-workgroup LDS FFT, 16 points per thread; 3 = the same with
-                                                    32 points per thread (N = 8192, 16384); 2 = radix-16 first stage +
-                                                    single-workgroup FFT of N/16 (N = 32768 .. 262144); 1 = four-step
-                                                    column / row kernels (N > 262144); 4 = N = 1024 .. 4096: large
+                                                    32 points per thread (N = 8192, 16384); 2 = radix-16 / 32 / 64 first
+                                                    stage + single-workgroup FFT of N/16 (N = 32768 .. 262144), N/32
+                                                    (524288) or N/64 (1048576) points; 4 = N = 1024 .. 4096: large
                                                     batches run two frames per workgroup in packed fp32 (lds / vgprs /
                                                     grid then describe that kernel), small ones the path-0 kernel */);
 

@@ -13,7 +13,6 @@
 
 #include "../../include/ksa.h"
 #include "ksa_dif16.hpp"
-#include "ksa_fourstep.hpp"
 #include "ksa_kernels.hpp"
 #include "ksa_kernels32.hpp"
 #include "ksa_kernels_pair.hpp"
@@ -104,8 +103,7 @@ struct ksa_engine {
   float* d_scan_send = nullptr;   // [nhalo][npasses][N] own bands packed for the right neighbours
   size_t scan_halo_cap = 0, scan_send_cap = 0;   // floats
   hipEvent_t ev_ready = nullptr, ev_copied = nullptr, ev_stream = nullptr;
-  ksa::FourStep four;           // N > 262144: four-step path (column / row kernels)
-  // 16384 < N <= 262144: radix-16 decimation in frequency in front of the single-workgroup kernel (ksa_dif16.hpp)
+  // N > 16384: radix-16 / 32 / 64 decimation in frequency in front of the single-workgroup kernel (ksa_dif16.hpp)
   int sub_n = 0;                // size of the single-workgroup transform: fft_size (path 0) or fft_size/16 (path 2)
   float2* d_dif_tw = nullptr;   // [6][N1]
   float2* d_dif_z = nullptr;    // [chunk][16][nwin][N1]
@@ -113,6 +111,7 @@ struct ksa_engine {
   float* d_ones = nullptr;      // [N1] taps of the second stage (the window was applied in the first)
   int* d_starts_b = nullptr;    // [nwin] w*N1
   int dif_chunk = 1;
+  int dif_radix = 16;           // first-stage radix: 16 (N <= 262144), 32 (524288), 64 (1048576)
   // bookkeeping
   long long frames_seen = 0;
   int hm_index = 0;
@@ -362,14 +361,23 @@ int run_dif16(ksa_engine* e, const SpecParams& p, int fmt) {
     a.u8_offset = p.u8_offset;
     a.u8_inv_scale = p.u8_inv_scale;
     a.z = e->d_dif_z;
-    const dim3 ga(n1 / 512, nwin, cf);     // two adjacent n1 per thread
-    if (fmt == KSA_FMT_C64) hipLaunchKernelGGL(ksa::dif16_kernel<ksa::FMT_C64>, ga, dim3(256), 0, e->stream, a);
-    else hipLaunchKernelGGL(ksa::dif16_kernel<ksa::FMT_U8>, ga, dim3(256), 0, e->stream, a);
+    const int R = e->dif_radix;
+    if (R == 16) {
+      const dim3 ga(n1 / 512, nwin, cf);     // two adjacent n1 per thread
+      if (fmt == KSA_FMT_C64) hipLaunchKernelGGL(ksa::dif16_kernel<ksa::FMT_C64>, ga, dim3(256), 0, e->stream, a);
+      else hipLaunchKernelGGL(ksa::dif16_kernel<ksa::FMT_U8>, ga, dim3(256), 0, e->stream, a);
+    } else {
+      const dim3 ga(n1 / 256, nwin, cf);     // one n1 per thread, 32 or 64 samples in registers
+      if (R == 32 && fmt == KSA_FMT_C64) hipLaunchKernelGGL((ksa::dif_wide_kernel<ksa::FMT_C64, 32>), ga, dim3(256), 0, e->stream, a);
+      else if (R == 32) hipLaunchKernelGGL((ksa::dif_wide_kernel<ksa::FMT_U8, 32>), ga, dim3(256), 0, e->stream, a);
+      else if (fmt == KSA_FMT_C64) hipLaunchKernelGGL((ksa::dif_wide_kernel<ksa::FMT_C64, 64>), ga, dim3(256), 0, e->stream, a);
+      else hipLaunchKernelGGL((ksa::dif_wide_kernel<ksa::FMT_U8, 64>), ga, dim3(256), 0, e->stream, a);
+    }
     SpecParams b{};
     b.iq = e->d_dif_z;
     b.frame_stride = (long long)nwin * n1;
     b.frame_len = nwin * n1;
-    b.nframes = cf * 16;
+    b.nframes = cf * R;
     b.nwin = nwin;
     b.starts = e->d_starts_b;      // w * N1 (a single window, RAW mode, starts at 0 too)
     b.window = e->d_ones;
@@ -384,6 +392,7 @@ int run_dif16(ksa_engine* e, const SpecParams& p, int fmt) {
     c.y = e->d_dif_y;
     c.n = n;
     c.n1 = n1;
+    c.radix = R;
     c.frame0 = f0;
     c.out_mode = p.out_mode;
     c.gain = p.gain;
@@ -395,7 +404,7 @@ int run_dif16(ksa_engine* e, const SpecParams& p, int fmt) {
     c.hm_ring = p.hm_ring;
     c.hm_index0 = p.hm_index0;
     c.hm_first = p.hm_first;
-    hipLaunchKernelGGL(ksa::dif16_finish_kernel, dim3(n1 / 64, cf), dim3(256), 0, e->stream, c);
+    hipLaunchKernelGGL(ksa::dif16_finish_kernel, dim3(n1 / (1024 / R), cf), dim3(256), 0, e->stream, c);
   }
   if (p.hm_w > 0 && n / p.hm_w > 1024)      // cells wider than the finish kernel's tile
     hipLaunchKernelGGL(ksa::rowmax_batch, dim3((p.hm_w + 255) / 256, p.nframes), dim3(256), 0, e->stream, p, n);
@@ -403,7 +412,7 @@ int run_dif16(ksa_engine* e, const SpecParams& p, int fmt) {
   return 0;
 }
 
-// Spectrum stage for a batch: either the single-workgroup LDS FFT or the four-step path.
+// Spectrum stage for a batch: the single-workgroup LDS FFT, behind a radix-16 / 32 / 64 first stage for N > 16384.
 int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int nframes, int out_mode,
                  float* out, bool with_hm, float* hm_rows) {
   const ksa_config& c = e->cfg;
@@ -450,10 +459,7 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
   hipEvent_t ea, eb;
   if (prof_begin(e, &ea, &eb)) return 1;
   int rc;
-  if (e->path == 1) {
-    rc = ksa::fourstep_run(e->four, p, fmt, e->stream, e->num_cu);
-    if (rc) return fail("four-step launch failed: %s", hipGetErrorString(hipGetLastError()));
-  } else if (e->path == 2) {
+  if (e->path == 2) {
     if ((rc = run_dif16(e, p, fmt))) return rc;
   } else {
     rc = fmt == KSA_FMT_C64 ? launch_spec_n<ksa::FMT_C64>(e, p, false) : launch_spec_n<ksa::FMT_U8>(e, p, false);
@@ -615,9 +621,10 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   if ((rc = upload(&e->d_start_last, cfg->window_starts + cfg->num_windows - 1, 1))) return bail(rc);
   if ((rc = upload(&e->d_window, cfg->window, (size_t)n))) return bail(rc);
 
-  if (n <= 262144) {
+  {
     e->path = n <= 16384 ? 0 : 2;
-    const int sn = e->path == 0 ? n : n / 16;     // the single-workgroup transform
+    e->dif_radix = n <= 262144 ? 16 : n == 524288 ? 32 : 64;
+    const int sn = e->path == 0 ? n : n / e->dif_radix;     // the single-workgroup transform
     e->sub_n = sn;
     const int pt = 16, lpt = 4;   // 16 points per thread, radix-16 passes (an 8-point / radix-8 plan measured 20 % slower)
     const bool fused_mid = tune_fused(sn), fused_last = tune_fused_last(sn);   // layouts must match ksa::Tune<N>
@@ -704,9 +711,10 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     if (e->path == 2) {
       const int n1 = sn, nw = cfg->num_windows;
       // first-stage output twiddles W_N^(n1*e), e = 1,2,3,4,8,12 (float64-generated); w^k2 = w^(k2&3) * w^(k2&12)
-      static const int ex[6] = {1, 2, 3, 4, 8, 12};
-      std::vector<float2> tw((size_t)6 * n1);
-      for (int r = 0; r < 6; ++r)
+      static const int ex[9] = {1, 2, 3, 4, 8, 12, 16, 32, 48};
+      const int nrows = e->dif_radix == 16 ? 6 : 9;
+      std::vector<float2> tw((size_t)nrows * n1);
+      for (int r = 0; r < nrows; ++r)
         for (int k = 0; k < n1; ++k) {
           const double ang = -2.0 * M_PI * (double)ex[r] * (double)k / (double)n;
           tw[(size_t)r * n1 + k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
@@ -734,13 +742,6 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
       if ((he2 = hipMalloc(reinterpret_cast<void**>(&e->d_dif_y), (size_t)e->dif_chunk * n * 4)) != hipSuccess)
         return bail(fail("hipMalloc for the second-stage output: %s", hipGetErrorString(he2)));
     }
-  } else {
-    e->path = 1;
-    if (ksa::fourstep_create(e->four, n, cfg->num_windows, cfg->max_frames, e->num_cu)) return bail(fail("four-step setup failed for fft_size %d: %s", n, hipGetErrorString(hipGetLastError())));
-    e->threads = e->four.threads;
-    e->lds_bytes = e->four.lds_bytes;
-    e->vgprs = e->four.vgprs;
-    e->blocks_per_cu = 1;
   }
 
   const size_t nn = (size_t)n;
@@ -756,7 +757,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   e->d_partial = e->d_xchg;
   if (cfg->hm_width) e->d_hm = e->d_xchg + 4 * nn;
   ALLOC(e->d_state, 4 * nn * 4);
-  if (e->path != 1) ALLOC(e->d_parts, (size_t)e->num_cu * e->blocks_per_cu * (size_t)e->sub_n * 4);
+  ALLOC(e->d_parts, (size_t)e->num_cu * e->blocks_per_cu * (size_t)e->sub_n * 4);
   if (cfg->scan_total_entries) {
     ALLOC(e->d_scan_state, (size_t)4 * cfg->scan_total_entries * 4);
     ALLOC(e->d_scan_hm, (size_t)KSA_HM_ROWS * cfg->scan_hm_width * 4);
@@ -780,7 +781,6 @@ void ksa_destroy(ksa_engine* e) {
                   e->d_iq_stage, e->d_frames, e->d_part, e->d_xchg, e->d_state, e->d_scan_state, e->d_scan_hm,
                   e->d_levels, e->d_parts, e->d_highs, e->d_scan_avg_rows, e->d_dif_tw, e->d_dif_z, e->d_dif_y, e->d_ones, e->d_starts_b};
   for (void* p : ptrs) if (p) hipFree(p);
-  ksa::fourstep_destroy(e->four);
   delete e;
 }
 

@@ -569,6 +569,27 @@ __global__ void combine_parts_kernel(const SpecParams p, int n) {
   *reinterpret_cast<float4*>(p.out + (long long)frame * n + sh) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// Waterfall cells (K:480) of finished dB rows: blockIdx.y = frame of the batch.  Used where the cell reduction does not
+// ride on the output stage: the window-split (latency) mode and cells wider than the large-transform finish tile.
+__global__ void rowmax_batch(const SpecParams p, int n) {
+  const int frame = blockIdx.y;
+  const int g = n / p.hm_w;
+  const float* row = p.out + (long long)frame * n;
+  for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < p.hm_w; cell += gridDim.x * blockDim.x) {
+    float hv = -__builtin_inff();
+    bool nan = false;
+    for (int i = 0; i < g; ++i) {
+      float v = row[cell * g + i];
+      if (p.adj) v -= p.adj[cell * g + i];
+      nan |= v != v;
+      hv = fmaxf(hv, v);
+    }
+    if (nan) hv = __builtin_nanf("");
+    if (p.hm_rows) p.hm_rows[(long long)frame * p.hm_w + cell] = hv;
+    if (p.hm_ring && frame >= p.hm_first) p.hm_ring[((p.hm_index0 + frame) % HM_ROWS) * p.hm_w + cell] = hv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // zeroSpanPlay: dB + waterfall row of spectra that are already linear magnitudes (K:469, K:480)
 struct DbRowParams {

@@ -110,8 +110,8 @@ def test_curscan_large_n_golden(ksa, tag):
 
 @pytest.mark.parametrize("tag", ["n32768_q05", "n65536_q025"])
 def test_curscan_four_step_golden(ksa, tag):
-    """16384 < N <= 262144 runs the radix-16 DIF stage in front of the single-workgroup kernel (path 2; larger N the
-    four-step kernels, path 1); config 5 geometry (65536, 75 % overlap, 29 windows)."""
+    """N > 16384 runs a radix-16 / 32 / 64 DIF stage in front of the single-workgroup kernel (path 2); config 5 geometry
+    (65536, 75 % overlap, 29 windows)."""
     g = golden("curscan_" + tag)
     n, q, full = int(g["fft_size"]), float(g["non_overlap"]), int(g["full"])
     x = orc.synth_iq(full, int(g["seed"])).astype(np.complex64)
@@ -126,7 +126,8 @@ def test_curscan_four_step_golden(ksa, tag):
         eng.close()
 
 
-@pytest.mark.parametrize("n,q,fmt", [(32768, 0.5, "c64"), (65536, 0.25, "u8"), (131072, 0.5, "c64"), (262144, 0.3, "u8"), (524288, 0.5, "c64"), (1048576, 0.5, "c64")])
+@pytest.mark.parametrize("n,q,fmt", [(32768, 0.5, "c64"), (65536, 0.25, "u8"), (131072, 0.5, "c64"), (262144, 0.3, "u8"), (524288, 0.5, "c64"), (1048576, 0.5, "c64"),
+                                     (524288, 0.3, "u8"), (1048576, 0.25, "u8")])
 def test_four_step_full_spectrum_vs_oracle(ksa, n, q, fmt):
     full = 2 * n
     x = orc.synth_iq(full, 4000 + (n >> 10))
@@ -493,10 +494,10 @@ def test_merge_gathered_refusals(ksa, torch_cuda):
     eng.close()
 
 
-@pytest.mark.parametrize("n,xres", [(128, 64), (64, 64), (1024, 512), (4096, 16), (16384, 32), (16384, 8192), (256, 4), (65536, 64), (65536, 16), (32768, 32768), (131072, 2048)])
+@pytest.mark.parametrize("n,xres", [(128, 64), (64, 64), (1024, 512), (4096, 16), (16384, 32), (16384, 8192), (256, 4), (65536, 64), (65536, 16), (32768, 32768), (131072, 2048), (524288, 512), (1048576, 64), (1048576, 4096)])
 def test_waterfall_cell_paths(ksa, torch_cuda, n, xres):
     """Every waterfall reduction path of the output stage: g = N/W of 1, 2, 4..256 (shuffles) and > 256 (LDS),
-    on the single-workgroup and the four-step kernels."""
+    on the single-workgroup kernels and behind the radix-16 / 32 / 64 first stages."""
     torch = torch_cuda
     full, frames = 2 * n, 3
     x = orc.synth_iq(full * frames, 900 + n + xres).astype(np.complex64).reshape(frames, full)
