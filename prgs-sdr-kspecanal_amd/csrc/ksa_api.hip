@@ -404,7 +404,10 @@ int run_dif16(ksa_engine* e, const SpecParams& p, int fmt) {
     c.hm_ring = p.hm_ring;
     c.hm_index0 = p.hm_index0;
     c.hm_first = p.hm_first;
-    hipLaunchKernelGGL(ksa::dif16_finish_kernel, dim3(n1 / (1024 / R), cf), dim3(256), 0, e->stream, c);
+    const dim3 gf(n1 / (1024 / R), cf);
+    if (R == 16) hipLaunchKernelGGL(ksa::dif16_finish_kernel<16>, gf, dim3(256), 0, e->stream, c);
+    else if (R == 32) hipLaunchKernelGGL(ksa::dif16_finish_kernel<32>, gf, dim3(256), 0, e->stream, c);
+    else hipLaunchKernelGGL(ksa::dif16_finish_kernel<64>, gf, dim3(256), 0, e->stream, c);
   }
   if (p.hm_w > 0 && n / p.hm_w > 1024)      // cells wider than the finish kernel's tile
     hipLaunchKernelGGL(ksa::rowmax_batch, dim3((p.hm_w + 255) / 256, p.nframes), dim3(256), 0, e->stream, p, n);

@@ -204,13 +204,14 @@ struct DifFinishParams {
 };
 
 // One workgroup = 1024/radix consecutive k1 x radix k2 = 1024 consecutive output bins of one frame.
+template <int R>
 __global__ __launch_bounds__(256) void dif16_finish_kernel(const DifFinishParams p) {
   __shared__ float tile[1024 + 64];          // [1024/R][R + 1]
   __shared__ float cellv[1024];
   const int tid = threadIdx.x;
   const int fr = blockIdx.y;                 // frame inside the chunk
   const int frame = p.frame0 + fr;
-  const int R = p.radix, KO = 1024 / R;
+  constexpr int KO = 1024 / R;
   const int k1_0 = blockIdx.x * KO;
   const int N = p.n, N1 = p.n1;
   const float* yf = p.y + (long long)fr * R * N1;
