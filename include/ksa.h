@@ -11,6 +11,8 @@
  * the engine's device.  One engine = one GPU; no concurrent calls on one engine (the reference is
  * single threaded: K:505, K:1118-1123).  All device work is enqueued on the engine's stream
  * (ksa_set_stream) and host-pointer entry points synchronise that stream before returning.
+ * Every entry point selects its engine's device for its own duration and hands the caller's current
+ * HIP device back on return.  The library reads no environment variable.
  * Device output buffers (spectra, waterfall rows) must be 16-byte aligned; IQ buffers sample aligned.
  */
 #ifndef KSA_H
@@ -22,7 +24,8 @@
 extern "C" {
 #endif
 
-#define KSA_ABI_VERSION 2 /* 2: ksa_set_adj takes its target; allreduce_state, host-pointer scan pass, sharded scan entries */
+#define KSA_ABI_VERSION 3 /* 2: ksa_set_adj takes its target; allreduce_state, host-pointer scan pass, sharded scan entries
+                             3: ksa_scan_spectra_dev, ksa_read_hm_rows, ksa_read_view; entry points restore the caller's current device */
 #define KSA_HM_ROWS 128 /* waterfall history depth: maxHM K:448, fftHMMax K:611 */
 
 /* d['curScanCumuMode'] K:31-34, K:58, consumed by data_cumu K:124-147 */
@@ -67,7 +70,8 @@ const char* ksa_last_error(void);
 int ksa_create(const ksa_config* cfg, ksa_engine** out);
 void ksa_destroy(ksa_engine* e);
 /* hip_stream: a hipStream_t (NULL = the device's default stream).  When the stream changes, work already
- * enqueued on the old one is ordered in front of whatever is enqueued on the new one (event wait). */
+ * enqueued on the old one is ordered in front of whatever is enqueued on the new one (event wait): a stream handed in
+ * here must therefore stay alive until the engine's next ksa_set_stream (or ksa_destroy). */
 int ksa_set_stream(ksa_engine* e, void* hip_stream);
 int ksa_synchronize(ksa_engine* e);
 
@@ -157,6 +161,12 @@ int ksa_scan_passes_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t 
                         int32_t nsteps, int32_t npasses, const uint8_t* step_ok);
 int ksa_scan_stitch_passes_dev(ksa_engine* e, const float* step_db_dev /* [npasses][nsteps][N] */,
                                int32_t nsteps, int32_t npasses);
+/* Spectrum stage of a scan alone (K:636-641): nframes capture blocks spaced frame_stride samples apart -> out_dev
+ * [nframes][N] after Clip2MinAmp + LogNoGain(infTo = 0); step_ok (host [nframes] or NULL): 0 marks a block whose tune
+ * failed -> the dummy band ones(fftSize) through the same two steps (K:637-639), written by the library on the engine's
+ * stream.  What a band-sharded driver calls per share of bands before ksa_scan_stitch_range_dev. */
+int ksa_scan_spectra_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride, int32_t nframes,
+                         const uint8_t* step_ok, float* out_dev);
 /* Band-sharded scan (SURVEY 8e "freq-band"): this engine owns the tuned bands [step_lo, step_hi) of every pass and
  * the elements [elem_lo, elem_hi) of the stitched range (normally [step_lo*hop, step_hi*hop), the last rank up to
  * totalEntries).  own_db_dev = [npasses][step_hi-step_lo][N] dB spectra of its bands (own_band_major != 0:
@@ -207,6 +217,18 @@ int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, fl
  * idx_host / lvl_host: [count]; *found = cells marked. */
 int ksa_read_highs(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, int32_t curve, double min_sep_cells,
                    int32_t count, int32_t* idx_host, float* lvl_host, int32_t* found);
+
+/* Rows [row0, row0 + nrows) (mod 128) of the waterfall ring (scan != 0: the scan's ring) -> out_host[nrows][width]:
+ * the one new row of a frame / pass instead of the whole 128-row buffer (K:480-481, K:697, K:729). */
+int ksa_read_hm_rows(ksa_engine* e, int32_t scan, int32_t row0, int32_t nrows, float* out_host);
+
+/* The per-frame plot hand-off in ONE call and one synchronisation (K:477-504 / K:669-697): the decimated curves
+ * (as ksa_read_levels -> levels_host[4][cells]), the peak markers of `curve` (as ksa_read_highs; count = 0 skips them)
+ * and the newest hm_rows rows of the waterfall ring, oldest first (-> hm_rows_host[hm_rows][width]; 0 skips them);
+ * *hm_index = ring position after the newest row.  Only cells-sized arrays cross PCIe: SURVEY 8 row f2. */
+int ksa_read_view(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, float* levels_host, int32_t curve,
+                  double min_sep_cells, int32_t count, int32_t* idx_host, float* lvl_host, int32_t* found,
+                  int32_t hm_rows, float* hm_rows_host, int32_t* hm_index);
 
 /* ---- pinned host memory for capture blocks (optional: any host pointer works, pinned ones copy faster) ------------ */
 int ksa_host_alloc(void** out, int64_t bytes);

@@ -4,10 +4,11 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# KSA_LIB: alternative build of the same ABI (kernel-variant experiments); default = the in-tree library
-LIB_PATH = os.environ.get("KSA_LIB") or os.path.join(HERE, "libksa.so")
+# The in-tree build, and nothing else: no environment variable selects another library or another kernel
+# (A/B runs of variant builds swap the file: tools/with_lib.sh).
+LIB_PATH = os.path.join(HERE, "libksa.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 HM_ROWS = 128
 CUMU = {"RAW": 0, "AVG": 1, "MAX": 2, "MIN": 3}
 FMT_C64, FMT_U8 = 0, 1
@@ -66,6 +67,7 @@ SIGNATURES = {
     "ksa_scan_stitch_dev": (C.c_int, [_P, _P, _I32]),
     "ksa_scan_passes_dev": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
     "ksa_scan_stitch_passes_dev": (C.c_int, [_P, _P, _I32, _I32]),
+    "ksa_scan_spectra_dev": (C.c_int, [_P, _P, _I32, _I64, _I32, _P, _P]),
     "ksa_scan_stitch_range_dev": (C.c_int, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "ksa_scan_rows_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I32)]),
     "ksa_scan_merge_rows_dev": (C.c_int, [_P, _P, _I32, _I32, _I32]),
@@ -77,6 +79,8 @@ SIGNATURES = {
     "ksa_scan_set_base_is_raw": (C.c_int, [_P, _I32]),
     "ksa_read_levels": (C.c_int, [_P, _I32, _I32, _I32, _P]),
     "ksa_read_highs": (C.c_int, [_P, _I32, _I32, _I32, _I32, C.c_double, _I32, _P, _P, C.POINTER(_I32)]),
+    "ksa_read_hm_rows": (C.c_int, [_P, _I32, _I32, _I32, _P]),
+    "ksa_read_view": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, C.c_double, _I32, _P, _P, C.POINTER(_I32), _I32, _P, C.POINTER(_I32)]),
     "ksa_host_alloc": (C.c_int, [C.POINTER(_P), _I64]),
     "ksa_host_free": (C.c_int, [_P]),
     "ksa_prof_enable": (C.c_int, [_P, _I32]),

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,24 @@ int fail(const char* fmt, ...) {
   } while (0)
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// Entry points run on their engine's device and hand the caller's current device back on every exit path (a process that
+// drives one engine per GPU, or torch beside libksa, keeps its own notion of "current").
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// A/B switches of the measurement builds (tools/variants.sh compiles with -DKSA_EXPERIMENTS).  The shipped library reads
+// no environment variable: which kernel a user runs depends on the engine's configuration only.
+#ifdef KSA_EXPERIMENTS
+const char* exp_env(const char* name) { return getenv(name); }
+#else
+constexpr const char* exp_env(const char*) { return nullptr; }
+#endif
 
 // default first-stage scratch per chunk of frames (ksa_dif16.hpp); tuned on MI355X, see DESIGN.md 4.2
 #ifndef KSA_DIF_SCRATCH_MB_DEFAULT
@@ -181,7 +200,12 @@ int launch_pair(ksa_engine* e, const SpecParams& p, bool cfg_only) {
 template <int N, int FMT, int RM>
 int launch_spec_t(ksa_engine* e, const SpecParams& p, bool configure_only) {
   // large batches of 1024 .. 4096-point transforms: two frames per workgroup in packed fp32
-  if constexpr (ksa::Plan<N>::S == 1 && ksa::Plan<N>::T <= 256 && ksa::Plan<N>::M >= 2) {
+#ifdef KSA_EXPERIMENTS
+  constexpr bool pair_size = ksa::Plan<N>::S == 1 && ksa::Plan<N>::T <= 256 && ksa::Plan<N>::M >= 2;   // 1024 .. 4096 (KSA_PAIR_ALL)
+#else
+  constexpr bool pair_size = N == 1024;     // where it measured faster: the only size the product instantiates
+#endif
+  if constexpr (pair_size) {
     if (e->pair_ok) {
       if (configure_only) {
         // every reuse variant a later batch can pick (RAW mode runs RM = 0 whatever the hops); the one in use last,
@@ -211,7 +235,7 @@ template <int N, int FMT, int RM, int CM>
 int launch_spec_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
   using P = ksa::Plan<N>;
   auto kfn = ksa::spectrum_kernel<N, FMT, RM, CM>;
-  static const int lds_pad = getenv("KSA_LDS_PAD_KB") ? atoi(getenv("KSA_LDS_PAD_KB")) * 1024 : 0;   // occupancy experiments
+  static const int lds_pad = exp_env("KSA_LDS_PAD_KB") ? atoi(exp_env("KSA_LDS_PAD_KB")) * 1024 : 0;   // occupancy experiments
   const int lds_bytes = ksa::Tune<N>::LDS_BYTES + lds_pad;
   if (configure_only) {
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -232,7 +256,7 @@ int launch_spec_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
   // small batches (the per-frame drop-in, one scan pass): split every frame's windows over several
   // workgroups so that the GPU is filled; the partial folds are combined by a second, tiny kernel
   // (pays from N = 1024 up: 84 -> 51 us per block at N=4096, 720 -> 117 us at N=16384; tiny transforms only lose the launches)
-  if (e->d_parts && N >= 1024 && !getenv("KSA_NO_SPLIT") && p.nwin > 1 && p.nframes * 2 <= capacity) {
+  if (e->d_parts && N >= 1024 && !exp_env("KSA_NO_SPLIT") && p.nwin > 1 && p.nframes * 2 <= capacity) {
     q.parts = std::min(p.nwin, capacity / p.nframes);
     q.part_out = e->d_parts;
   }
@@ -281,12 +305,12 @@ int launch_spec32_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
   }
   const int capacity = e->num_cu * e->blocks_per_cu;
   SpecParams q = p;
-  if (e->d_parts && !getenv("KSA_NO_SPLIT") && p.nwin > 1 && p.nframes * 2 <= capacity) {   // window-split (latency) mode
+  if (e->d_parts && !exp_env("KSA_NO_SPLIT") && p.nwin > 1 && p.nframes * 2 <= capacity) {   // window-split (latency) mode
     q.parts = std::min(p.nwin, capacity / p.nframes);
     q.part_out = e->d_parts;
   }
   int grid = std::max(1, std::min(q.nframes * std::max(1, q.parts), capacity));
-  if (const char* g = getenv("KSA_GRID")) grid = std::max(1, std::min(grid, atoi(g)));   // measurement: fewer persistent workgroups
+  if (const char* g = exp_env("KSA_GRID")) grid = std::max(1, std::min(grid, atoi(g)));   // measurement: fewer persistent workgroups
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::T), P::LDS_BYTES, e->stream, q);
   if (q.parts > 1) {
     hipLaunchKernelGGL(ksa::combine_parts_kernel, dim3((N / 4 + 63) / 64, q.nframes), dim3(64), 0, e->stream, q, N);
@@ -322,8 +346,10 @@ int launch_spec_n(ksa_engine* e, const SpecParams& p, bool cfg_only) {
     case 1024: return launch_spec_rm<1024, FMT>(e, p, cfg_only, rm);
     case 2048: return launch_spec_rm<2048, FMT>(e, p, cfg_only, rm);
     case 4096: return launch_spec_rm<4096, FMT>(e, p, cfg_only, rm);
+#ifdef KSA_EXPERIMENTS   // the 16-point plan at these sizes is reachable through KSA_PLAN16 only
     case 8192: return launch_spec_rm<8192, FMT>(e, p, cfg_only, rm);
     case 16384: return launch_spec_rm<16384, FMT>(e, p, cfg_only, rm);
+#endif
     default: return fail("fft_size %d has no single-workgroup plan", e->sub_n);
   }
 }
@@ -469,7 +495,7 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
     if (rc) return rc;
   }
 #ifdef KSA_STAMPS
-  if (const char* path = getenv("KSA_STAMPS_FILE")) {
+  if (const char* path = exp_env("KSA_STAMPS_FILE")) {
     hipStreamSynchronize(e->stream);
     std::vector<unsigned long long> h(dbg_n);
     hipMemcpy(h.data(), dbg, dbg_n * 8, hipMemcpyDeviceToHost);
@@ -549,7 +575,8 @@ int scan_reset(ksa_engine* e) {
   const ksa_config& c = e->cfg;
   if (!c.scan_total_entries) return fail("engine was created without scan geometry");
   // K:603-608: Cur = Max = Avg = dB(minAmp4Clip), Min = dB(1.0); K:613-614 ring = minAmp4Clip (linear)
-  const float floor_db = (float)(10.0 * std::log10((double)c.min_amp) - (double)c.gain);
+  float floor_db = (float)(10.0 * std::log10((double)c.min_amp) - (double)c.gain);
+  if (std::isinf(floor_db)) floor_db = 0.f;      // infTo = 0 (K:604 -> K:110-111): minAmp4Clip 0 starts the curves at 0 dB
   const float one_db = (float)(10.0 * std::log10(1.0) - (double)c.gain);
   const long long t = c.scan_total_entries;
   if (fill(e, e->d_scan_state, t, floor_db)) return 1;
@@ -608,6 +635,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
   if (cfg->device < 0 || cfg->device >= ndev) return fail("device %d not present (%d visible)", cfg->device, ndev);
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(cfg->device));
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, cfg->device));
@@ -637,11 +665,11 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
     const int r0 = 1 << (log2n - lpt * (m - 1));
     std::vector<float2> mid, last;
     int pcur = r0;
-    e->plan32 = (sn == 8192 || sn == 16384) && !getenv("KSA_PLAN16");   // KSA_PLAN16: A/B switch back to the 16-point plan
+    e->plan32 = (sn == 8192 || sn == 16384) && !exp_env("KSA_PLAN16");   // KSA_PLAN16 (experiments build): back to the 16-point plan
     // Two frames per workgroup in packed fp32 (ksa_kernels_pair.hpp).  Measured against the one-frame kernel on MI355X
     // (tools/pair_sweep.sh, hops 0.5 / 0.25 / 0.1): N = 1024 +14..+30 %, N = 2048 -3..-5 %, N = 4096 0..-5 % -- on by
     // default for 1024 only.  KSA_PAIR_ALL enables it for 1024 .. 4096, KSA_NO_PAIR disables it (A/B switches).
-    e->pair_ok = e->path == 0 && !getenv("KSA_NO_PAIR") && (sn == 1024 || (getenv("KSA_PAIR_ALL") && sn >= 1024 && sn <= 4096));
+    e->pair_ok = e->path == 0 && !exp_env("KSA_NO_PAIR") && (sn == 1024 || (exp_env("KSA_PAIR_ALL") && sn >= 1024 && sn <= 4096));
     if (e->plan32) {
       // folded twiddles of dft16_fused for a base twiddle of `beta` turns: w^4, w^8, w^12, then w^n2 * W16^(n2*k1)
       auto fused15 = [](double beta, int e) {
@@ -706,7 +734,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
       for (int i = 2; i < cfg->num_windows; ++i) same &= cfg->window_starts[i] - cfg->window_starts[i - 1] == hop;
       if (same && (hop == n / 2 || hop == n / 4)) e->reuse_m = hop / (n / pt);
     }
-    if (getenv("KSA_NO_REUSE")) e->reuse_m = 0;   // A/B switch for measurements
+    if (exp_env("KSA_NO_REUSE")) e->reuse_m = 0;   // A/B switch of the experiments build
     SpecParams dummy{};
     dummy.nwin = cfg->num_windows;
     if ((rc = launch_spec_n<ksa::FMT_C64>(e, dummy, true))) return bail(rc);
@@ -733,7 +761,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
       // 32-bit offsets inside the kernels: a pseudo frame is nwin*N1 complex points addressed in bytes
       if ((long long)nw * n1 >= (1ll << 28)) return bail(fail("num_windows %d x fft_size/16 %d exceeds 2^28 points per frame", nw, n1));
       size_t budget = (size_t)KSA_DIF_SCRATCH_MB_DEFAULT << 20;
-      if (const char* mb = getenv("KSA_FS_SCRATCH_MB")) {        // A/B switch for measurements; nonsense keeps the default
+      if (const char* mb = exp_env("KSA_FS_SCRATCH_MB")) {       // A/B switch of the experiments build; nonsense keeps the default
         const long v = atol(mb);
         if (v >= 1 && v <= (256l << 10)) budget = (size_t)v << 20;
       }
@@ -775,6 +803,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
 
 void ksa_destroy(ksa_engine* e) {
   if (!e) return;
+  DeviceGuard dev_guard;
   hipSetDevice(e->cfg.device);
   hipDeviceSynchronize();
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -792,6 +821,9 @@ int ksa_set_stream(ksa_engine* e, void* hip_stream) {
   hipStream_t ns = reinterpret_cast<hipStream_t>(hip_stream);
   if (ns == e->stream) return 0;
   // engine-owned buffers (state, scratch, rings) may still be in use on the old stream: order the new one behind it
+  // (an event is recorded on the OLD stream, so a stream handed in here must stay alive until the next ksa_set_stream /
+  //  ksa_destroy of this engine)
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   if (!e->ev_stream) HIP_OK(hipEventCreateWithFlags(&e->ev_stream, hipEventDisableTiming));
   HIP_OK(hipEventRecord(e->ev_stream, e->stream));
@@ -810,12 +842,14 @@ int ksa_curscan_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t fram
                     int32_t out_mode, float* out_dev) {
   if (!e || !iq_dev || !out_dev) return fail("null argument");
   if (out_mode < KSA_OUT_LINEAR || out_mode > KSA_OUT_DB_CLIP) return fail("unknown out_mode %d", out_mode);
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   return run_spectrum(e, iq_dev, fmt, frame_stride, nframes, out_mode, out_dev, false, nullptr);
 }
 
 static int curscan_host(ksa_engine* e, const void* iq_host, int fmt, float* mag_host) {
   if (!e || !iq_host || !mag_host) return fail("null argument");
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   HIP_OK(hipMemcpyAsync(e->d_iq_stage, iq_host, (size_t)e->cfg.full_size * sample_bytes(fmt), hipMemcpyHostToDevice, e->stream));
   if (run_spectrum(e, e->d_iq_stage, fmt, 0, 1, KSA_OUT_LINEAR, e->d_frames, false, nullptr)) return 1;
@@ -831,6 +865,7 @@ int ksa_frames_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame
                    int64_t first_index, int64_t total_frames, float* cur_db_dev, float* hm_rows_dev, int32_t commit) {
   if (!e || !iq_dev) return fail("null argument");
   if (first_index < 0 || first_index + nframes > total_frames) return fail("batch [%lld,+%d) outside run of %lld frames", (long long)first_index, nframes, (long long)total_frames);
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   float* db = cur_db_dev ? cur_db_dev : e->d_frames;
   if (run_spectrum(e, iq_dev, fmt, frame_stride, nframes, KSA_OUT_DB, db, e->cfg.hm_width > 0, hm_rows_dev)) return 1;
@@ -842,6 +877,7 @@ int ksa_frames_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame
 
 static int frame_host(ksa_engine* e, const void* iq_host, int fmt) {
   if (!e || !iq_host) return fail("null argument");
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   HIP_OK(hipMemcpyAsync(e->d_iq_stage, iq_host, (size_t)e->cfg.full_size * sample_bytes(fmt), hipMemcpyHostToDevice, e->stream));
   if (ksa_frames_dev(e, e->d_iq_stage, fmt, 0, 1, 0, 1, nullptr, nullptr, 1)) return 1;
@@ -854,6 +890,7 @@ int ksa_frame_u8(ksa_engine* e, const uint8_t* iq_host) { return frame_host(e, i
 
 int ksa_frame_spectrum(ksa_engine* e, const float* mag_host) {
   if (!e || !mag_host) return fail("null argument");
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   const int n = e->cfg.fft_size;
   float* lin = reinterpret_cast<float*>(e->d_iq_stage);  // full_size*8 bytes >= N*4
@@ -899,6 +936,7 @@ int ksa_merge_gathered_dev(ksa_engine* e, const float* gathered_dev, int32_t wor
   if (e->pending_frames != frames_per_rank)
     return fail("ksa_merge_gathered_dev: %d frames pending, frames_per_rank says %d", e->pending_frames, frames_per_rank);
   if (hm_index0 < 0 || hm_index0 >= KSA_HM_ROWS) return fail("hm_index0 %d outside 0..127", hm_index0);
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   const int n = e->cfg.fft_size, w = e->cfg.hm_width;
   const long long stride = 4ll * n + (long long)KSA_HM_ROWS * w;
@@ -915,6 +953,7 @@ int ksa_merge_gathered_dev(ksa_engine* e, const float* gathered_dev, int32_t wor
 int ksa_commit(ksa_engine* e, int64_t total_frames) {
   if (!e) return fail("null engine");
   if (e->pending_frames <= 0) return fail("ksa_commit without a pending ksa_frames_dev(commit=0)");
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   return do_commit(e, total_frames, e->pending_frames);
 }
@@ -930,6 +969,7 @@ int ksa_set_flags(ksa_engine* e, int32_t b_max, int32_t b_min, int32_t b_avg) {
 int ksa_set_adj(ksa_engine* e, int32_t scan, const float* adj_host, int32_t n) {
   if (!e) return fail("null engine");
   if (scan && !e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   HIP_OK(hipStreamSynchronize(e->stream));
   float** slot = scan ? &e->d_scan_adj : &e->d_adj;
@@ -943,6 +983,7 @@ int ksa_set_adj(ksa_engine* e, int32_t scan, const float* adj_host, int32_t n) {
 
 int ksa_reset_state(ksa_engine* e) {
   if (!e) return fail("null engine");
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   HIP_OK(hipMemsetAsync(e->d_state, 0, (size_t)4 * e->cfg.fft_size * 4, e->stream));
   if (e->d_hm) HIP_OK(hipMemsetAsync(e->d_hm, 0, (size_t)KSA_HM_ROWS * e->cfg.hm_width * 4, e->stream));  // np.zeros K:456
@@ -956,6 +997,7 @@ int ksa_reset_state(ksa_engine* e) {
 int ksa_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg, float* hm, int32_t* hm_index,
                    int64_t* frames_seen) {
   if (!e) return fail("null engine");
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   const size_t nb = (size_t)e->cfg.fft_size * 4;
   float* dst[4] = {cur, max, min, avg};
@@ -997,7 +1039,7 @@ static int scan_stitch(ksa_engine* e, const float* step_db_dev, int nsteps, int 
   if (nsteps < 1 || npasses < 1) return fail("nsteps and npasses must be >= 1");
   if (step_hi < 0) step_hi = nsteps;
   if (elem_hi < 0) elem_hi = c.scan_total_entries;
-  HIP_OK(hipSetDevice(c.device));
+  HIP_OK(hipSetDevice(c.device));          // (the exported caller holds the DeviceGuard)
   ksa::StitchParams s{};
   s.step_db = step_db_dev;
   s.halo_db = halo_db_dev;
@@ -1079,6 +1121,7 @@ int ksa_scan_stitch_range_dev(ksa_engine* e, const float* own_db_dev, int32_t ow
     if (nhalo > 0 && !halo_db_dev) return fail("null halo_db_dev");
   }
   const float* own = own_db_dev ? own_db_dev : e->d_scan_state;   // (an engine that owns no band reads nothing)
+  DeviceGuard dev_guard;
   return scan_stitch(e, own, nsteps, npasses, true, halo_db_dev, nhalo, step_lo, step_hi, elem_lo, elem_hi, own_band_major != 0);
 }
 
@@ -1097,6 +1140,7 @@ int ksa_scan_merge_rows_dev(ksa_engine* e, const float* gathered_dev, int32_t wo
   if (world < 1) return fail("world %d < 1", world);
   if (rows != e->scan_rows || npasses != e->scan_rows_passes)
     return fail("ksa_scan_merge_rows_dev: %d rows of %d passes pending, call says %d of %d", e->scan_rows, e->scan_rows_passes, rows, npasses);
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(c.device));
   const int cells = rows * c.scan_hm_width;
   hipLaunchKernelGGL(ksa::scan_merge_rows_kernel, dim3((cells + 255) / 256), dim3(256), 0, e->stream, gathered_dev, world,
@@ -1148,12 +1192,22 @@ static int gather_all(ksa_engine* const* h, int n, size_t nfloats, float* (*bloc
 }
 
 // Direct xGMI copies between the engines' GPUs where the hardware allows them (hipMemcpyPeerAsync works either way,
-// through host staging otherwise).  Best effort: "already enabled" and "not supported" are not errors here.
+// through host staging otherwise).  Best effort: "already enabled" and "not supported" are not errors here.  Every
+// ordered device pair is tried ONCE per process (a bit per pair), not on every multi-engine call.
 static void enable_peer_access(ksa_engine* const* h, int n) {
+  static std::mutex mu;
+  static std::vector<unsigned char> tried;       // [a * ndev + b]
+  static int ndev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ndev) {
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { ndev = 0; (void)hipGetLastError(); return; }
+    tried.assign((size_t)ndev * ndev, 0);
+  }
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) {
       const int a = h[i]->cfg.device, b = h[j]->cfg.device;
-      if (a == b) continue;
+      if (a == b || a >= ndev || b >= ndev || tried[(size_t)a * ndev + b]) continue;
+      tried[(size_t)a * ndev + b] = 1;
       int can = 0;
       if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
       if (hipSetDevice(a) == hipSuccess) (void)hipDeviceEnablePeerAccess(b, 0);
@@ -1176,6 +1230,8 @@ static int check_handles(ksa_engine* const* h, int n) {
 }
 
 int ksa_allreduce_state(ksa_engine* const* handles, int32_t n, int32_t frames_per_rank, int32_t hm_index0) {
+  DeviceGuard dev_guard;
+  // everything is validated before the first copy or launch: a refusal leaves every engine as it was
   if (check_handles(handles, n)) return 1;
   if (frames_per_rank < 1) return fail("frames_per_rank %d < 1", frames_per_rank);
   if (hm_index0 < 0 || hm_index0 >= KSA_HM_ROWS) return fail("hm_index0 %d outside 0..127", hm_index0);
@@ -1190,22 +1246,32 @@ int ksa_allreduce_state(ksa_engine* const* handles, int32_t n, int32_t frames_pe
 }
 
 int ksa_scan_allstitch(ksa_engine* const* handles, int32_t n, float* const* own_db_dev, int32_t nsteps, int32_t npasses) {
+  DeviceGuard dev_guard;
   if (check_handles(handles, n)) return 1;
   if (!own_db_dev) return fail("null own_db_dev");
   const ksa_config& c = handles[0]->cfg;
   if (!c.scan_total_entries) return fail("engines were created without scan geometry");
   if (nsteps < 1 || npasses < 1) return fail("nsteps and npasses must be >= 1");
   const size_t band = (size_t)npasses * c.fft_size;   // floats of one band over the batch
+  const int reach = (c.fft_size + c.scan_hop - 1) / c.scan_hop - 1;   // bands in front of a band that still overlap it
   auto lo_of = [&](int r) { return (int)((long long)nsteps * r / n); };
+  // 0. every pointer and range is checked before the first launch: a refusal at rank k must not leave ranks < k with
+  //    their pass counters advanced and their state stitched while the ring is never merged
+  for (int r = 0; r < n; ++r) {
+    const int lo = lo_of(r), hi = lo_of(r + 1);
+    if (hi > lo && !own_db_dev[r]) return fail("own_db_dev[%d] is null (rank %d owns bands %d..%d)", r, r, lo, hi - 1);
+    if (handles[r]->scan_rows > 0) return fail("engine %d still holds unmerged partial rows of an earlier batch", r);
+    const long long e_lo = (long long)lo * c.scan_hop;
+    if (r < n - 1 && hi > lo && e_lo > c.scan_total_entries) return fail("rank %d's bands start past the stitched range", r);
+  }
   // 1. every engine packs the bands its right neighbours need ([band][npasses][N]) behind its spectrum stage
   for (int r = 0; r < n; ++r) {
     ksa_engine* e = handles[r];
     const int lo = lo_of(r), hi = lo_of(r + 1), mine = hi - lo;
     HIP_OK(hipSetDevice(e->cfg.device));
     if (ensure_events(e)) return 1;
-    const int keep = std::min(mine, (c.fft_size + c.scan_hop - 1) / c.scan_hop - 1);   // its last bands may be someone's halo
+    const int keep = std::min(mine, reach);            // its last bands may be someone's halo
     if (keep > 0 && r + 1 < n) {
-      if (!own_db_dev[r]) return fail("own_db_dev[%d] is null", r);
       if (ensure(&e->d_scan_send, &e->scan_send_cap, (size_t)keep * band)) return 1;
       for (int b = 0; b < keep; ++b)     // band hi-keep+b of every pass -> send[b][pass][N]
         HIP_OK(hipMemcpy2DAsync(e->d_scan_send + (size_t)b * band, (size_t)c.fft_size * 4,
@@ -1226,7 +1292,7 @@ int ksa_scan_allstitch(ksa_engine* const* handles, int32_t n, float* const* own_
       while (src > 0 && lo_of(src) > j) --src;
       ksa_engine* s = handles[src];
       const int shi = lo_of(src + 1), smine = shi - lo_of(src);
-      const int skeep = std::min(smine, (c.fft_size + c.scan_hop - 1) / c.scan_hop - 1);
+      const int skeep = std::min(smine, reach);
       const int b = j - (shi - skeep);                 // position of band j in src's send block
       if (b < 0) return fail("internal: band %d is not in rank %d's send block", j, src);
       HIP_OK(hipStreamWaitEvent(e->stream, s->ev_ready, 0));
@@ -1246,6 +1312,7 @@ int ksa_scan_allstitch(ksa_engine* const* handles, int32_t n, float* const* own_
 }
 
 int ksa_scan_gather_state(ksa_engine* const* handles, int32_t n, int32_t nsteps, float* cur, float* max, float* min, float* avg) {
+  DeviceGuard dev_guard;
   if (check_handles(handles, n)) return 1;
   const ksa_config& c = handles[0]->cfg;
   if (!c.scan_total_entries) return fail("engines were created without scan geometry");
@@ -1272,6 +1339,7 @@ static int scan_pass_host(ksa_engine* e, const void* iq_host, int fmt, int nstep
   if (!e || !iq_host) return fail("null argument");
   if (!e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
   if (nsteps < 1 || nsteps > e->cfg.max_frames) return fail("nsteps %d outside 1..max_frames(%d)", nsteps, e->cfg.max_frames);
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   const size_t bytes = (size_t)nsteps * e->cfg.full_size * sample_bytes(fmt);
   if (ensure(reinterpret_cast<unsigned char**>(&e->d_scan_stage), &e->scan_stage_cap, bytes)) return 1;
@@ -1300,11 +1368,34 @@ int ksa_host_free(void* p) {
 }
 
 int ksa_scan_stitch_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps) {
+  DeviceGuard dev_guard;
   return scan_stitch(e, step_db_dev, nsteps, 1);
 }
 
 int ksa_scan_stitch_passes_dev(ksa_engine* e, const float* step_db_dev, int32_t nsteps, int32_t npasses) {
+  DeviceGuard dev_guard;
   return scan_stitch(e, step_db_dev, nsteps, npasses);
+}
+
+// Clip2MinAmp + LogNoGain spectra of `frames` capture blocks (K:640-641) into out_dev[frames][N]; a block whose
+// step_ok entry is 0 is replaced by the dummy band: ones(fftSize) through the same two steps (K:637-641)
+static int scan_spectra(ksa_engine* e, const void* iq_dev, int fmt, long long frame_stride, int frames, const uint8_t* step_ok,
+                        float* out_dev) {
+  if (run_spectrum(e, iq_dev, fmt, frame_stride, frames, KSA_OUT_DB_CLIP, out_dev, false, nullptr)) return 1;
+  if (step_ok) {
+    const float v = (float)(10.0 * std::log10(std::max(1.0, (double)e->cfg.min_amp)) - (double)e->cfg.gain);
+    for (long long s = 0; s < frames; ++s)
+      if (!step_ok[s] && fill(e, out_dev + (size_t)s * e->cfg.fft_size, e->cfg.fft_size, v)) return 1;
+  }
+  return 0;
+}
+
+int ksa_scan_spectra_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride, int32_t nframes,
+                         const uint8_t* step_ok, float* out_dev) {
+  if (!e || !iq_dev || !out_dev) return fail("null argument");
+  DeviceGuard dev_guard;
+  HIP_OK(hipSetDevice(e->cfg.device));
+  return scan_spectra(e, iq_dev, fmt, frame_stride, nframes, step_ok, out_dev);
 }
 
 int ksa_scan_passes_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame_stride, int32_t nsteps,
@@ -1314,14 +1405,9 @@ int ksa_scan_passes_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t 
   if (nsteps < 1 || npasses < 1) return fail("nsteps and npasses must be >= 1");
   const long long frames = (long long)nsteps * npasses;
   if (frames > e->cfg.max_frames) return fail("%d passes x %d steps exceed max_frames %d", npasses, nsteps, e->cfg.max_frames);
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (run_spectrum(e, iq_dev, fmt, frame_stride, (int)frames, KSA_OUT_DB_CLIP, e->d_frames, false, nullptr)) return 1;
-  if (step_ok) {
-    // dummy band: ones(fftSize) through Clip2MinAmp + LogNoGain (K:637-641)
-    const float v = (float)(10.0 * std::log10(std::max(1.0, (double)e->cfg.min_amp)) - (double)e->cfg.gain);
-    for (long long s = 0; s < frames; ++s)
-      if (!step_ok[s] && fill(e, e->d_frames + (size_t)s * e->cfg.fft_size, e->cfg.fft_size, v)) return 1;
-  }
+  if (scan_spectra(e, iq_dev, fmt, frame_stride, (int)frames, step_ok, e->d_frames)) return 1;
   return scan_stitch(e, e->d_frames, nsteps, npasses);
 }
 
@@ -1334,6 +1420,7 @@ int ksa_scan_read_state(ksa_engine* e, float* cur, float* max, float* min, float
                         int64_t* passes) {
   if (!e) return fail("null engine");
   if (!e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   const size_t t = (size_t)e->cfg.scan_total_entries;
   float* dst[4] = {cur, max, min, avg};
@@ -1361,6 +1448,7 @@ int ksa_scan_set_base_is_raw(ksa_engine* e, int32_t on) {
 
 int ksa_scan_reset(ksa_engine* e) {
   if (!e) return fail("null engine");
+  DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   return scan_reset(e);
 }
@@ -1370,7 +1458,7 @@ static int levels_to_scratch(ksa_engine* e, int scan, int mode, int cells) {
   const int n = scan ? e->cfg.scan_total_entries : e->cfg.fft_size;
   if (scan && !n) return fail("engine was created without scan geometry");
   if (cells < 1 || n % cells) return fail("cells %d must divide %d", cells, n);
-  HIP_OK(hipSetDevice(e->cfg.device));
+  HIP_OK(hipSetDevice(e->cfg.device));     // (the exported caller holds the DeviceGuard)
   if (!e->d_levels || e->levels_cap < cells) {
     if (e->d_levels) hipFree(e->d_levels);
     e->d_levels = nullptr;
@@ -1386,6 +1474,7 @@ static int levels_to_scratch(ksa_engine* e, int scan, int mode, int cells) {
 
 int ksa_read_levels(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, float* out_host) {
   if (!e || !out_host) return fail("null argument");
+  DeviceGuard dev_guard;
   if (levels_to_scratch(e, scan, mode, cells)) return 1;
   HIP_OK(hipMemcpyAsync(out_host, e->d_levels, (size_t)4 * cells * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_OK(hipStreamSynchronize(e->stream));
@@ -1398,6 +1487,7 @@ int ksa_read_highs(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, int
   if (curve < 0 || curve > 3) return fail("curve %d (0 cur, 1 max, 2 min, 3 avg)", curve);
   if (count < 1 || count > ksa::HIGHS_MAX) return fail("marker count %d outside 1..%d", count, ksa::HIGHS_MAX);
   if (!(min_sep_cells >= 0.0)) return fail("min_sep_cells must be >= 0");
+  DeviceGuard dev_guard;
   if (levels_to_scratch(e, scan, mode, cells)) return 1;
   if (!e->d_highs) HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_highs), (2 * ksa::HIGHS_MAX + 1) * 4));
   ksa::HighsParams h{};
@@ -1418,6 +1508,71 @@ int ksa_read_highs(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, int
     idx_host[i] = host[i];
     memcpy(&lvl_host[i], &host[ksa::HIGHS_MAX + i], 4);
   }
+  return 0;
+}
+
+// rows [row0, row0 + nrows) (mod 128) of a waterfall ring -> host
+static int copy_ring_rows(ksa_engine* e, int scan, int row0, int nrows, float* out_host) {
+  const float* ring = scan ? e->d_scan_hm : e->d_hm;
+  const int w = scan ? e->cfg.scan_hm_width : e->cfg.hm_width;
+  if (!ring || w < 1) return fail("engine has no %s waterfall", scan ? "scan" : "zeroSpan");
+  if (row0 < 0 || row0 >= KSA_HM_ROWS || nrows < 0 || nrows > KSA_HM_ROWS) return fail("ring rows [%d,+%d) outside 0..127", row0, nrows);
+  const int first = std::min(nrows, KSA_HM_ROWS - row0);
+  if (first > 0) HIP_OK(hipMemcpyAsync(out_host, ring + (size_t)row0 * w, (size_t)first * w * 4, hipMemcpyDeviceToHost, e->stream));
+  if (nrows > first)
+    HIP_OK(hipMemcpyAsync(out_host + (size_t)first * w, ring, (size_t)(nrows - first) * w * 4, hipMemcpyDeviceToHost, e->stream));
+  return 0;
+}
+
+int ksa_read_hm_rows(ksa_engine* e, int32_t scan, int32_t row0, int32_t nrows, float* out_host) {
+  if (!e || !out_host) return fail("null argument");
+  if (scan && !e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
+  DeviceGuard dev_guard;
+  HIP_OK(hipSetDevice(e->cfg.device));
+  if (copy_ring_rows(e, scan, row0, nrows, out_host)) return 1;
+  HIP_OK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int ksa_read_view(ksa_engine* e, int32_t scan, int32_t mode, int32_t cells, float* levels_host, int32_t curve,
+                  double min_sep_cells, int32_t count, int32_t* idx_host, float* lvl_host, int32_t* found,
+                  int32_t hm_rows, float* hm_rows_host, int32_t* hm_index) {
+  if (!e || !levels_host) return fail("null argument");
+  if (count > 0 && (!idx_host || !lvl_host || !found)) return fail("null marker outputs");
+  if (count < 0 || count > ksa::HIGHS_MAX) return fail("marker count %d outside 0..%d", count, ksa::HIGHS_MAX);
+  if (count > 0 && (curve < 0 || curve > 3)) return fail("curve %d (0 cur, 1 max, 2 min, 3 avg)", curve);
+  if (count > 0 && !(min_sep_cells >= 0.0)) return fail("min_sep_cells must be >= 0");
+  if (hm_rows < 0 || hm_rows > KSA_HM_ROWS || (hm_rows > 0 && !hm_rows_host)) return fail("hm_rows %d outside 0..128 or null buffer", hm_rows);
+  if (scan && !e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
+  DeviceGuard dev_guard;
+  if (levels_to_scratch(e, scan, mode, cells)) return 1;       // (selects the device)
+  HIP_OK(hipMemcpyAsync(levels_host, e->d_levels, (size_t)4 * cells * 4, hipMemcpyDeviceToHost, e->stream));
+  int host[2 * ksa::HIGHS_MAX + 1];
+  if (count > 0) {
+    if (!e->d_highs) HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_highs), (2 * ksa::HIGHS_MAX + 1) * 4));
+    ksa::HighsParams h{};
+    h.lv = e->d_levels + (size_t)curve * cells;
+    h.cells = cells;
+    h.min_sep = min_sep_cells;
+    h.count = count;
+    h.idx = e->d_highs;
+    h.lvl = reinterpret_cast<float*>(e->d_highs + ksa::HIGHS_MAX);
+    h.found = e->d_highs + 2 * ksa::HIGHS_MAX;
+    hipLaunchKernelGGL(ksa::highs_kernel, dim3(1), dim3(1024), 0, e->stream, h);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(host, e->d_highs, sizeof host, hipMemcpyDeviceToHost, e->stream));
+  }
+  const int idx = scan ? e->scan_hm_index : e->hm_index;       // the ring position AFTER the newest row
+  if (hm_rows > 0 && copy_ring_rows(e, scan, ((idx - hm_rows) % KSA_HM_ROWS + KSA_HM_ROWS) % KSA_HM_ROWS, hm_rows, hm_rows_host)) return 1;
+  HIP_OK(hipStreamSynchronize(e->stream));
+  if (count > 0) {
+    *found = host[2 * ksa::HIGHS_MAX];
+    for (int i = 0; i < *found; ++i) {
+      idx_host[i] = host[i];
+      memcpy(&lvl_host[i], &host[ksa::HIGHS_MAX + i], 4);
+    }
+  }
+  if (hm_index) *hm_index = idx;
   return 0;
 }
 

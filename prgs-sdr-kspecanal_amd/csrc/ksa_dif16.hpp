@@ -229,11 +229,7 @@ __global__ __launch_bounds__(256) void dif16_finish_kernel(const DifFinishParams
   for (int j = 0; j < 4; ++j) {
     const int i = tid + 256 * j;             // k = R*k1_0 + i
     float lin = tile[(i / R) * (R + 1) + (i % R)];
-    float o = lin;
-    if (p.out_mode != OUT_LINEAR) {
-      if (p.out_mode == OUT_DB_CLIP) lin = fmaxf(lin, p.min_amp);
-      o = db_of(lin, p.gain);
-    }
+    const float o = p.out_mode != OUT_LINEAR ? out_db(lin, p.out_mode, p.gain, p.min_amp) : lin;
     orow[i] = o;
     if (hm_here) cellv[i] = p.adj ? o - p.adj[sh0 + i] : o;
   }

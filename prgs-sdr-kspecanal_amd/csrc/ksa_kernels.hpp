@@ -52,6 +52,25 @@ struct SpecParams {
 // denormal magnitudes (< 1.2e-38, below -380 dB) read as zero.
 __device__ __forceinline__ float db_of(float lin, float gain) { return fmaf(__builtin_amdgcn_logf(lin), 3.01029995663981195f, -gain); }
 
+// np.max / np.min semantics (K:141-143, K:195): a NaN on either side wins.  v_max_f32 / v_min_f32 return the other operand.
+__device__ __forceinline__ float nan_max(float a, float b) { return __builtin_isunordered(a, b) ? __builtin_nanf("") : fmaxf(a, b); }
+__device__ __forceinline__ float nan_min(float a, float b) { return __builtin_isunordered(a, b) ? __builtin_nanf("") : fminf(a, b); }
+// The MAX fold of |X|^2 (K:141): both operands are +0 .. +inf or NaN, and on those the unsigned order of the bit patterns
+// is the float order with every NaN (either sign) above +inf -- one v_max_u32 is the NaN-propagating maximum.
+__device__ __forceinline__ float nan_max_nonneg(float a, float b) {
+  const unsigned x = __float_as_uint(a), y = __float_as_uint(b);
+  return __uint_as_float(x > y ? x : y);
+}
+// Clip2MinAmp (np.clip, K:100-101): NaN stays NaN (fmaxf would return min_amp)
+__device__ __forceinline__ float clip_min(float lin, float min_amp) { return lin < min_amp ? min_amp : lin; }
+// dB value of one bin in out_mode units: zeroSpan keeps -inf (K:469), the scan replaces +-inf by 0 (infTo = 0, K:641 -> K:110-111)
+__device__ __forceinline__ float out_db(float lin, int out_mode, float gain, float min_amp) {
+  if (out_mode == OUT_DB_CLIP) lin = clip_min(lin, min_amp);
+  float o = db_of(lin, gain);
+  if (out_mode == OUT_DB_CLIP && fabsf(o) == __builtin_inff()) o = 0.0f;
+  return o;
+}
+
 // Output stage of one frame (rows A7 tail, A8, A9, A12): slot combine, 2*winAdj/N scale, fftshift,
 // LogNoGain / Clip2MinAmp, store, waterfall cell max.  red = [S][N] floats in LDS (natural bin order).
 // Each thread takes 4 consecutive bins per step: one ds_read_b128, one 16-byte store, and the
@@ -73,8 +92,8 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
       for (int s2 = 1; s2 < S; ++s2) {
         const float4 x = red4[s2 * (N / 4) + q];
         if (p.cumu == CUMU_AVG) { r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-        else if (p.cumu == CUMU_MAX) { r.x = fmaxf(r.x, x.x); r.y = fmaxf(r.y, x.y); r.z = fmaxf(r.z, x.z); r.w = fmaxf(r.w, x.w); }
-        else { r.x = fminf(r.x, x.x); r.y = fminf(r.y, x.y); r.z = fminf(r.z, x.z); r.w = fminf(r.w, x.w); }
+        else if (p.cumu == CUMU_MAX) { r.x = nan_max(r.x, x.x); r.y = nan_max(r.y, x.y); r.z = nan_max(r.z, x.z); r.w = nan_max(r.w, x.w); }
+        else { r.x = nan_min(r.x, x.x); r.y = nan_min(r.y, x.y); r.z = nan_min(r.z, x.z); r.w = nan_min(r.w, x.w); }
       }
     }
     float o[4] = {r.x, r.y, r.z, r.w};
@@ -82,11 +101,7 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
     for (int u = 0; u < 4; ++u) {
       float lin = p.cumu == CUMU_AVG ? o[u] : __builtin_amdgcn_sqrtf(o[u]);
       lin *= p.scale;
-      o[u] = lin;
-      if (p.out_mode != OUT_LINEAR) {
-        if (p.out_mode == OUT_DB_CLIP) lin = fmaxf(lin, p.min_amp);
-        o[u] = db_of(lin, p.gain);
-      }
+      o[u] = p.out_mode != OUT_LINEAR ? out_db(lin, p.out_mode, p.gain, p.min_amp) : lin;
     }
     const int sh = (4 * q + N / 2) & (N - 1);   // fftshift keeps runs of 4 together
     *reinterpret_cast<float4*>(orow + sh) = make_float4(o[0], o[1], o[2], o[3]);
@@ -95,20 +110,25 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
         const float4 a = *reinterpret_cast<const float4*>(p.adj + sh);
         o[0] -= a.x; o[1] -= a.y; o[2] -= a.z; o[3] -= a.w;
       }
+      // the cell maximum is np.max (K:195 through K:480): a NaN bin -- -inf minus a -inf baseline, K:405 -- makes the cell NaN
       if (!hm_fast) {
         *reinterpret_cast<float4*>(red + S * N + sh) = make_float4(o[0], o[1], o[2], o[3]);  // second plane
       } else if (g == 1) {
         if (hm_row) *reinterpret_cast<float4*>(hm_row + sh) = make_float4(o[0], o[1], o[2], o[3]);
         if (hm_ring) *reinterpret_cast<float4*>(hm_ring + sh) = make_float4(o[0], o[1], o[2], o[3]);
       } else if (g == 2) {
-        const float2 c = make_float2(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
+        const float2 c = make_float2(nan_max(o[0], o[1]), nan_max(o[2], o[3]));
         if (hm_row) *reinterpret_cast<float2*>(hm_row + sh / 2) = c;
         if (hm_ring) *reinterpret_cast<float2*>(hm_ring + sh / 2) = c;
       } else {
-        // g/4 consecutive lanes hold the g consecutive bins of one cell
+        // g/4 consecutive lanes hold the g consecutive bins of one cell; NaN travels as a flag beside the v_max_f32 tree
         float hv = fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
+        const bool bad = __builtin_isunordered(o[0], o[1]) | __builtin_isunordered(o[2], o[3]);
         for (int m = 1; m < g / 4; m <<= 1) hv = fmaxf(hv, __shfl_xor(hv, m));
+        const unsigned long long nb = __ballot(bad);
         if ((tid & (g / 4 - 1)) == 0) {
+          const unsigned long long cell = g >= 256 ? ~0ull : (((1ull << (g / 4)) - 1ull) << (tid & 63));
+          if (nb & cell) hv = __builtin_nanf("");
           if (hm_row) hm_row[sh / g] = hv;
           if (hm_ring) hm_ring[sh / g] = hv;
         }
@@ -121,7 +141,13 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
 #pragma unroll 1
     for (int cell = tid; cell < p.hm_w; cell += T) {
       float hv = hmbuf[cell * g];
-      for (int i = 1; i < g; ++i) hv = fmaxf(hv, hmbuf[cell * g + i]);
+      bool bad = hv != hv;
+      for (int i = 1; i < g; ++i) {
+        const float x = hmbuf[cell * g + i];
+        bad |= x != x;
+        hv = fmaxf(hv, x);
+      }
+      if (bad) hv = __builtin_nanf("");
       if (hm_row) hm_row[cell] = hv;
       if (hm_ring) hm_ring[cell] = hv;
     }
@@ -486,12 +512,12 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
 #pragma unroll
           for (int i = 0; i < 16; ++i)
             acc[i] = fmaf(w, __builtin_amdgcn_sqrtf(fmaf(v[i].x, v[i].x, v[i].y * v[i].y)), acc[i]);
-        } else if (cm == CUMU_MAX) {
+        } else if (cm == CUMU_MAX) {      // np.max / np.min of K:141-143: a NaN window keeps the bin NaN
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
+          for (int i = 0; i < 16; ++i) acc[i] = nan_max_nonneg(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
         } else {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = fminf(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
+          for (int i = 0; i < 16; ++i) acc[i] = nan_min(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
         }
       }
       KSA_STAMP(7);
@@ -521,8 +547,8 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
           for (int s2 = 1; s2 < S; ++s2) {
             const float4 x = red4[s2 * (N / 4) + q];
             if (p.cumu == CUMU_AVG) { r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-            else if (p.cumu == CUMU_MAX) { r.x = fmaxf(r.x, x.x); r.y = fmaxf(r.y, x.y); r.z = fmaxf(r.z, x.z); r.w = fmaxf(r.w, x.w); }
-            else { r.x = fminf(r.x, x.x); r.y = fminf(r.y, x.y); r.z = fminf(r.z, x.z); r.w = fminf(r.w, x.w); }
+            else if (p.cumu == CUMU_MAX) { r.x = nan_max(r.x, x.x); r.y = nan_max(r.y, x.y); r.z = nan_max(r.z, x.z); r.w = nan_max(r.w, x.w); }
+            else { r.x = nan_min(r.x, x.x); r.y = nan_min(r.y, x.y); r.z = nan_min(r.z, x.z); r.w = nan_min(r.w, x.w); }
           }
         }
         dst[q] = r;
@@ -551,19 +577,15 @@ __global__ void combine_parts_kernel(const SpecParams p, int n) {
   for (int part = 1; part < p.parts; ++part) {
     const float4 x = src[(long long)part * (n / 4)];
     if (p.cumu == CUMU_AVG) { r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-    else if (p.cumu == CUMU_MAX) { r.x = fmaxf(r.x, x.x); r.y = fmaxf(r.y, x.y); r.z = fmaxf(r.z, x.z); r.w = fmaxf(r.w, x.w); }
-    else { r.x = fminf(r.x, x.x); r.y = fminf(r.y, x.y); r.z = fminf(r.z, x.z); r.w = fminf(r.w, x.w); }
+    else if (p.cumu == CUMU_MAX) { r.x = nan_max(r.x, x.x); r.y = nan_max(r.y, x.y); r.z = nan_max(r.z, x.z); r.w = nan_max(r.w, x.w); }
+    else { r.x = nan_min(r.x, x.x); r.y = nan_min(r.y, x.y); r.z = nan_min(r.z, x.z); r.w = nan_min(r.w, x.w); }
   }
   float o[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     float lin = p.cumu == CUMU_AVG ? o[u] : __builtin_amdgcn_sqrtf(o[u]);
     lin *= p.scale;
-    o[u] = lin;
-    if (p.out_mode != OUT_LINEAR) {
-      if (p.out_mode == OUT_DB_CLIP) lin = fmaxf(lin, p.min_amp);
-      o[u] = db_of(lin, p.gain);
-    }
+    o[u] = p.out_mode != OUT_LINEAR ? out_db(lin, p.out_mode, p.gain, p.min_amp) : lin;
   }
   const int sh = (4 * q + n / 2) & (n - 1);
   *reinterpret_cast<float4*>(p.out + (long long)frame * n + sh) = make_float4(o[0], o[1], o[2], o[3]);
@@ -640,9 +662,6 @@ struct AccParams {
   int chunk;         // frames per partial
   float* part;       // [chunks][3][N] : max, min, sum
 };
-
-__device__ __forceinline__ float nan_max(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
-__device__ __forceinline__ float nan_min(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fminf(a, b); }
 
 // One thread = 4 consecutive bins (16-byte loads), one blockIdx.y = one chunk of frames.
 __global__ void accumulate_partial_kernel(const AccParams p) {

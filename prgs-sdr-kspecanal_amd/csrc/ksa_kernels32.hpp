@@ -260,10 +260,10 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
             acc[b * 16 + i] = fmaf(wgt, __builtin_amdgcn_sqrtf(fmaf(u[i].x, u[i].x, u[i].y * u[i].y)), acc[b * 16 + i]);
         } else if (cm == CUMU_MAX) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[b * 16 + i] = fmaxf(acc[b * 16 + i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
+          for (int i = 0; i < 16; ++i) acc[b * 16 + i] = nan_max_nonneg(acc[b * 16 + i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
         } else {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[b * 16 + i] = fminf(acc[b * 16 + i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
+          for (int i = 0; i < 16; ++i) acc[b * 16 + i] = nan_min(acc[b * 16 + i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
         }
       }
     }

@@ -161,13 +161,13 @@ __global__ __launch_bounds__(Plan<N>::T, 2) void spectrum_pair_kernel(const Spec
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const v2f m2 = fma2(v[i].x, v[i].x, v[i].y * v[i].y);
-          acc[i] = v2f{fmaxf(acc[i].x, m2.x), fmaxf(acc[i].y, m2.y)};
+          acc[i] = v2f{nan_max_nonneg(acc[i].x, m2.x), nan_max_nonneg(acc[i].y, m2.y)};
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const v2f m2 = fma2(v[i].x, v[i].x, v[i].y * v[i].y);
-          acc[i] = v2f{fminf(acc[i].x, m2.x), fminf(acc[i].y, m2.y)};
+          acc[i] = v2f{nan_min(acc[i].x, m2.x), nan_min(acc[i].y, m2.y)};
         }
       }
     }

@@ -26,6 +26,12 @@ import torch.distributed as dist
 HM_ROWS = 128
 
 
+def global_rank(group, rank_in_group):
+    """dist.broadcast / isend / irecv / P2POp address peers by their rank in the DEFAULT group even when `group=` is
+    given; everything in this module computes ranks inside the group it was handed."""
+    return rank_in_group if group is None else dist.get_global_rank(group, rank_in_group)
+
+
 def merge_partials(partial, group=None):
     """partial: float32[4, N] = {max, cur-or--inf, -min, weighted sum} of this rank's chunk, in place.
     The minimum travels negated so that ONE MAX all-reduce covers three rows; one SUM covers the fourth."""
@@ -50,7 +56,7 @@ def ring_owner(idx0, frames_per_rank, world):
 def merge_ring(ring, idx0, frames_per_rank, world, group=None):
     """ring: float32[128, W] of this rank (rows written at globally correct slots), merged in place."""
     if frames_per_rank >= HM_ROWS:
-        dist.broadcast(ring, src=world - 1, group=group)   # the last 128 frames all live on the last rank
+        dist.broadcast(ring, src=global_rank(group, world - 1), group=group)   # the last 128 frames all live on the last rank
         return ring
     gathered = [torch.empty_like(ring) for _ in range(world)]
     dist.all_gather(gathered, ring.contiguous(), group=group)
@@ -93,7 +99,7 @@ def merge_gathered_reference(gathered, n, hm_w, idx0, frames_per_rank):
 class ShardedZeroSpan:
     """Drives one engine per rank; with world == 1 it is a plain frames_dev call on the engine's own stream.  Stream
     contract of the collective path: every step points the engine at torch's current stream (_follow_current_stream),
-    the stream RCCL orders against."""
+    the stream RCCL orders against.  `group`: ranks are counted INSIDE it (rank / world = position in / size of the group)."""
 
     def __init__(self, engine, rank=0, world=1, group=None, always_collective=False):
         self.eng, self.rank, self.world, self.group = engine, rank, world, group
@@ -165,7 +171,7 @@ def _follow_current_stream(eng):
 
 class _P2P:
     """One halo exchange in flight: every receive and send is posted at construction, finish() waits for all of them.
-    ops_*: [(tensor, peer)].  NCCL (= RCCL) moves device tensors directly and asynchronously (one ncclGroupStart/End:
+    ops_*: [(tensor, peer)], peer = rank INSIDE `group` (translated to the global rank the P2P calls want).  NCCL (= RCCL) moves device tensors directly and asynchronously (one ncclGroupStart/End:
     the transfers run on RCCL's stream behind the work already queued on the current stream, kernels launched afterwards
     overlap them; finish() makes the current stream wait); gloo (CPU rehearsals, several ranks on one GPU) goes through
     host copies of device tensors."""
@@ -174,6 +180,8 @@ class _P2P:
         self.staged, self.reqs = [], []
         if not ops_send and not ops_recv:
             return
+        ops_send = [(t, global_rank(group, peer)) for t, peer in ops_send]
+        ops_recv = [(t, global_rank(group, peer)) for t, peer in ops_recv]
         if dist.get_backend(group) == "nccl":
             ops = [dist.P2POp(dist.irecv, t, peer, group) for t, peer in ops_recv]
             ops += [dist.P2POp(dist.isend, t, peer, group) for t, peer in ops_send]
@@ -248,23 +256,21 @@ class ShardedScan:
     def run_passes(self, iq_local, fmt, nsteps, npasses, step_ok=None):
         """iq_local: [npasses][hi-lo] capture blocks of this rank (pass-major), on its GPU.  step_ok (optional):
         [npasses][hi-lo], 0 marks a band whose tune failed -> dummy ones (K:637-639)."""
-        from ._lib import OUT_DB_CLIP
         eng = self.eng
         if self._key != (nsteps, npasses):
             self._setup(nsteps, npasses)
         mine, n = self.hi - self.lo, eng.fft_size
         if self.world > 1:
-            _follow_current_stream(eng)
-        dummy = float(10.0 * np.log10(max(1.0, eng.min_amp)) - eng.gain)          # ones -> Clip2MinAmp -> LogNoGain, K:637-641
-        bad = None
+            _follow_current_stream(eng)      # the halo copies and the collectives below are torch work on engine output
+        # a band whose tune failed becomes the dummy band (K:637-641): written by the library on the engine's stream
+        # (ksa_scan_spectra_dev), so no torch kernel touches engine output outside the collective path
+        ok = None
         if step_ok is not None and mine > 0:
-            bad = torch.as_tensor(np.asarray(step_ok).reshape(npasses, mine) == 0, device=self.own.device)
-            bad = bad if bool(bad.any()) else None
+            ok = np.ascontiguousarray(np.asarray(step_ok).reshape(npasses, mine) != 0, dtype=np.uint8)
+            ok = None if bool(ok.all()) else ok
         if self.world == 1:
             if mine > 0:
-                eng.curscan_dev(iq_local, fmt, npasses * mine, self.own, out_mode=OUT_DB_CLIP)
-                if bad is not None:
-                    self.own[:, :mine][bad] = dummy
+                eng.scan_spectra_dev(iq_local, fmt, npasses * mine, self.own, step_ok=ok)
             eng.scan_stitch_dev(self.own, nsteps, npasses)
             return
 
@@ -281,16 +287,13 @@ class ShardedScan:
             for b in first + rest:
                 if xchg is None and b in rest:
                     xchg = post_halo()                 # everything a neighbour waits for is queued: it travels under the rest
-                eng.curscan_dev(blocks[:, b], fmt, npasses, self.own[b], out_mode=OUT_DB_CLIP, frame_stride=mine * eng.full_size)
-                if bad is not None and bool(bad[:, b].any()):
-                    self.own[b][bad[:, b]] = dummy
+                eng.scan_spectra_dev(blocks[:, b], fmt, npasses, self.own[b], step_ok=None if ok is None else ok[:, b],
+                                     frame_stride=mine * eng.full_size)
             if xchg is None:
                 xchg = post_halo()
         else:
             if mine > 0:
-                eng.curscan_dev(iq_local, fmt, npasses * mine, self.own, out_mode=OUT_DB_CLIP)
-                if bad is not None:
-                    self.own[:, :mine][bad] = dummy
+                eng.scan_spectra_dev(iq_local, fmt, npasses * mine, self.own, step_ok=ok)
             xchg = post_halo()
         xchg.finish()
         for _, j, c0, buf in self.recv:

@@ -287,6 +287,15 @@ class SpectrumEngine:
             raise KsaError("step_ok has %d entries for %d steps" % (ok.size, a.shape[0]))
         check(fn(self._h, _ptr(a), int(a.shape[0]), _ptr(ok)))
 
+    def scan_spectra_dev(self, iq, fmt, nframes, out, step_ok=None, frame_stride=None):
+        """Spectrum stage of a scan alone (K:636-641): Clip2MinAmp + LogNoGain spectra of nframes blocks into the device
+        buffer `out`; step_ok (host, optional): 0 -> the dummy band, written by the library on the engine's stream."""
+        stride = self.full_size if frame_stride is None else int(frame_stride)
+        ok = None if step_ok is None else np.ascontiguousarray(step_ok, dtype=np.uint8)
+        if ok is not None and ok.size != int(nframes):
+            raise KsaError("step_ok has %d entries for %d blocks" % (ok.size, nframes))
+        check(lib.ksa_scan_spectra_dev(self._h, _ptr(iq), fmt, stride, int(nframes), _ptr(ok), _ptr(out)))
+
     def scan_stitch_dev(self, step_db, nsteps, npasses=1):
         check(lib.ksa_scan_stitch_passes_dev(self._h, _ptr(step_db), int(nsteps), int(npasses)))
 
@@ -357,6 +366,31 @@ class SpectrumEngine:
         check(lib.ksa_read_highs(self._h, int(bool(scan)), code, int(cells), cv, float(min_sep), int(count),
                                  _ptr(idx), _ptr(lvl), C.byref(found)))
         return idx[:found.value].copy(), lvl[:found.value].astype(np.float64)
+
+    def hm_rows(self, row0, nrows, scan=False):
+        """Rows [row0, row0+nrows) (mod 128) of the waterfall ring: float64[nrows, width]."""
+        w = self.scan_hm_width if scan else self.hm_width
+        out = np.empty((int(nrows), w), dtype=np.float32)
+        check(lib.ksa_read_hm_rows(self._h, int(bool(scan)), int(row0) % HM_ROWS, int(nrows), _ptr(out)))
+        return out.astype(np.float64)
+
+    def view(self, cells, mode="AVG", curve=None, min_sep=0.0, count=0, hm_rows=1, scan=False):
+        """The per-frame plot hand-off in one call (ksa_read_view): (levels float64[4, cells], marker cells, marker
+        levels, newest `hm_rows` ring rows oldest first float64[hm_rows, width], hm_index).  Only cells-sized data
+        crosses PCIe."""
+        code = {"AVG": 0, "MAX": 1, "MIN": 2}[mode.upper()]
+        cv = {"cur": 0, "max": 1, "min": 2, "avg": 3}[(curve or "cur").lower()]
+        count = int(count) if curve is not None else 0
+        w = self.scan_hm_width if scan else self.hm_width
+        lv = np.empty((4, int(cells)), dtype=np.float32)
+        idx = np.empty(max(count, 1), dtype=np.int32)
+        lvl = np.empty(max(count, 1), dtype=np.float32)
+        rows = np.empty((int(hm_rows), w), dtype=np.float32)
+        found, hm_index = C.c_int32(0), C.c_int32()
+        check(lib.ksa_read_view(self._h, int(bool(scan)), code, int(cells), _ptr(lv), cv, float(min_sep), count, _ptr(idx),
+                                _ptr(lvl), C.byref(found), int(hm_rows), _ptr(rows) if hm_rows else None, C.byref(hm_index)))
+        return (lv.astype(np.float64), idx[:found.value].copy(), lvl[:found.value].astype(np.float64),
+                rows.astype(np.float64), hm_index.value)
 
     # -- measurement ------------------------------------------------------------------------------------
     def prof_enable(self, on=True):

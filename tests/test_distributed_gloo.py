@@ -141,11 +141,13 @@ class FakeScanEngine:
     def set_stream(self, s):
         pass
 
-    def curscan_dev(self, iq, fmt, nframes, out, out_mode=None, frame_stride=None):
+    def scan_spectra_dev(self, iq, fmt, nframes, out, step_ok=None, frame_stride=None):
         x = iq.numpy().reshape(nframes, self.full_size, 2)
         o = out.view(-1, self.fft_size)
         for f in range(nframes):
             lin = orc.curscan(x[f, :, 0] + 1j * x[f, :, 1], self.fft_size, self.q_win, self.win, "AVG")
+            if step_ok is not None and not step_ok[f]:
+                lin = np.ones(self.fft_size)                              # dummy band, K:637-639
             o[f] = torch.from_numpy(orc.log_no_gain(orc.clip2minamp(lin, self.min_amp), self.gain, inf_to=0).astype(np.float32))
 
     def scan_stitch_range_dev(self, own, halo, nhalo, lo, hi, nsteps, npasses, e_lo, e_hi, own_band_major=False):
@@ -210,25 +212,57 @@ def _scan_case(name):
     return n, q, fs, start, end, steps, full, passes, x
 
 
-def _sharded_scan_worker(rank, world, port, name, out_path):
+def _bad_steps(steps, passes):
+    """Tunes that fail in the dummy-band variant of a case: [2][passes][steps] flags, 0 = failed."""
+    ok = np.ones((2, passes, steps), dtype=np.uint8)
+    ok[0, 0, steps // 2] = 0
+    ok[1, passes - 1, 0] = 0
+    ok[1, 0, steps - 1] = 0
+    return ok
+
+
+def _sharded_scan_worker(rank, world, port, name, out_path, members=None, dummy=False):
+    """members: run the scan on a SUB-GROUP of the job (its ranks, in group order); the other ranks only take part in
+    creating the group.  Peers inside distributed.py are ranks of the group, not of the job."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ksa_dist = __import__("importlib").import_module("prgs-sdr-kspecanal_amd.distributed")
+    group, grank, gworld = None, rank, world
+    if members is not None:
+        group = dist.new_group(list(members))
+        if rank not in members:
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        grank, gworld = dist.get_rank(group), dist.get_world_size(group)     # (new_group orders its members by global rank)
     n, q, fs, start, end, steps, full, passes, x = _scan_case(name)
     total = int((end - start) / fs) * n
     eng = FakeScanEngine(n, full, 0.5, "hanning", GAIN, 1e-7, 32, total, q)
-    run = ksa_dist.ShardedScan(eng, rank, world, device="cpu")
-    lo, hi = ksa_dist.step_range(steps, rank, world)
+    run = ksa_dist.ShardedScan(eng, grank, gworld, group=group, device="cpu")
+    lo, hi = ksa_dist.step_range(steps, grank, gworld)
+    bad = _bad_steps(steps, passes) if dummy else None
     for batch in range(2):
         iq = torch.view_as_real(torch.from_numpy(np.ascontiguousarray(x[batch][:, lo:hi]))).contiguous()
-        run.run_passes(iq, 0, steps, passes)
+        run.run_passes(iq, 0, steps, passes, step_ok=None if bad is None else bad[batch][:, lo:hi])
     st = run.gather_state(steps)
     cb = run.collective_bytes()
-    assert cb["halo_recv"] == sum(passes * (n - c0) * 4 for _, _, c0 in ksa_dist.halo_plan(steps, world, n, eng.scan_hop)[rank]["recv"])
+    assert cb["halo_recv"] == sum(passes * (n - c0) * 4 for _, _, c0 in ksa_dist.halo_plan(steps, gworld, n, eng.scan_hop)[grank]["recv"])
     np.savez(out_path % rank, hm_index=st["hm_index"], **{k: st[k] for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg", "fftHM")})
+    if members is not None:
+        # the time-chunk merges on the same sub-group: the broadcast of merge_ring (>= 128 frames per rank) addresses
+        # its source by global rank too
+        part = torch.full((4, 8), float(grank))
+        ksa_dist.merge_partials(part, group)
+        assert part[0, 0] == gworld - 1 and part[3, 0] == sum(range(gworld))
+        ring = torch.full((128, 4), float(grank))
+        ksa_dist.merge_ring(ring, 0, 130, gworld, group)
+        assert bool((ring == gworld - 1).all())
+        ring = torch.full((128, 4), float(grank))
+        ksa_dist.merge_ring(ring, 0, 3, gworld, group)
+        assert ring[:3 * gworld, 0].tolist() == [float(r) for r in range(gworld) for _ in range(3)]
     dist.barrier()
     dist.destroy_process_group()
 
@@ -253,6 +287,29 @@ def test_band_sharded_scan_driver_over_gloo(tmp_path, name, world):
             assert np.max(np.abs(got[k] - want)) < 2e-4, (k, r)          # float32 transport of the dB spectra
         assert np.max(np.abs(got["fftHM"][:2 * passes] - ref.hm[:2 * passes])) < 2e-4, r
         assert np.allclose(got["fftHM"][2 * passes:], ref.hm[2 * passes:])
+
+
+@pytest.mark.parametrize("name,world,members,dummy", [("half", 4, (1, 3), False), ("eighth", 5, (4, 0, 2), False), ("half", 3, None, True)])
+def test_band_sharded_scan_on_a_sub_group_and_with_failed_tunes(tmp_path, name, world, members, dummy):
+    """halo peers are ranks INSIDE the group the driver was given; isend / irecv / broadcast want global
+    ranks -- a job of 4 (5) ranks runs the scan on the sub-group [1, 3] ([4, 0, 2]: group order differs from job order).
+    And a scan with failed tunes (step_ok): the dummy band (K:637-639) is written on the engine's side of the driver."""
+    load_pkg()
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_sharded_scan_worker, args=(world, _free_port(), name, out, members, dummy), nprocs=world, join=True)
+    n, q, fs, start, end, steps, full, passes, x = _scan_case(name)
+    ref = orc.ScanState(n, start, end, fs, GAIN, 1e-7, 32, scan_non_overlap=q)
+    win = orc.window_table("hanning", n)
+    bad = _bad_steps(steps, passes) if dummy else np.ones((2, passes, steps), dtype=np.uint8)
+    for batch in range(2):
+        for p in range(passes):
+            ref.run_pass([orc.curscan(x[batch, p, s], n, 0.5, win, "AVG") if bad[batch, p, s] else None for s in range(steps)])
+    for r in (members if members is not None else range(world)):
+        got = np.load(out % r)
+        assert int(got["hm_index"]) == ref.hm_index
+        for k, want in (("Fft.Cur", ref.cur), ("Fft.Max", ref.max), ("Fft.Min", ref.min), ("Fft.Avg", ref.avg)):
+            assert np.max(np.abs(got[k] - want)) < 2e-4, (k, r)
+        assert np.max(np.abs(got["fftHM"][:2 * passes] - ref.hm[:2 * passes])) < 2e-4, r
 
 
 def test_scan_band_shares_and_halo_plan():

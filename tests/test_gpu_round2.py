@@ -379,51 +379,4 @@ def test_bench_secondary_configs_one_gpu(cfg, extra):
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
 
 
-# ------------------------------------------------------------------------- two frames per workgroup (packed fp32)
-@pytest.mark.parametrize("n,q,fmt,mode", [(1024, 0.5, "c64", "AVG"), (1024, 0.1, "u8", "MAX"), (4096, 0.5, "c64", "AVG"),
-                                          (2048, 0.25, "c64", "MIN"), (4096, 0.1, "u8", "AVG")])
-def test_pair_kernel_matches_single(ksa, torch_cuda, n, q, fmt, mode, monkeypatch):
-    """spectrum_pair_kernel (two frames per workgroup, v_pk_*_f32) against spectrum_kernel on the same batch (odd frame
-    count, above the switch-over): every frame, the state and the waterfall rows agree to fp32 rounding (the pair
-    kernel's last pass builds its twiddles from 6 instead of 15 table entries), and both match the oracle."""
-    torch = torch_cuda
-    full = n * 8
-    frames = 2 * 256 * 2 + 513                       # above the switch-over (2 * CUs * workgroups per CU), odd
-    distinct = 37
-    x = orc.synth_iq(full * distinct, 4321 + n).astype(np.complex64).reshape(distinct, full)
-    idx = np.arange(frames) % distinct
-    if fmt == "u8":
-        dev = torch.from_numpy(orc.quantize_u8((x * 0.7).reshape(-1)).reshape(distinct, 2 * full)[idx]).cuda()
-        code = ksa.FMT_U8
-    else:
-        dev = torch.view_as_real(torch.from_numpy(x[idx])).cuda()
-        code = ksa.FMT_C64
-    outs = []
-    for env in ({"KSA_PAIR_ALL": "1"}, {"KSA_NO_PAIR": "1"}):
-        for k in ("KSA_PAIR_ALL", "KSA_NO_PAIR"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="kaiser", cumu_mode=mode, xres=256, max_frames=frames)
-        assert eng.kernel_info()["path"] == (4 if "KSA_PAIR_ALL" in env else 0)
-        db = torch.empty((frames, n), dtype=torch.float32, device="cuda")
-        rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
-        eng.frames_dev(dev, code, frames, cur_db=db, hm_rows=rows)
-        st = eng.state()
-        outs.append((db.cpu().numpy(), rows.cpu().numpy(), st))
-        eng.close()
-    (da, ra, sa), (db_, rb, sb) = outs
-    assert_lin(10 ** (da / 10), 10 ** (db_.astype(np.float64) / 10), tol=2e-6, what="pair vs single frames")
-    top = np.max(db_, axis=1, keepdims=True)
-    strong = db_ > top - 30
-    assert np.max(np.abs(da[strong] - db_[strong])) < 1e-3
-    assert np.max(np.abs(ra - rb)) < 1e-3                       # waterfall rows = per-cell maxima
-    for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg"):
-        assert_db(sa[k], sb[k], what="pair vs single " + k)
-    assert np.max(np.abs(sa["fftHM"] - sb["fftHM"])) < 1e-3 and sa["hm_index"] == sb["hm_index"]
-    # and against the oracle on a few frames
-    win = orc.window_table("kaiser", n)
-    for f in (0, 1, frames - 1):
-        src = x[idx[f]] if fmt == "c64" else orc.unpack_u8(orc.quantize_u8(x[idx[f]] * 0.7))
-        want = orc.log_no_gain(orc.curscan(src, n, q, win, mode), 19.1)
-        assert_db(da[f], want, what="pair frame %d" % f)
+# (the two-frames-per-workgroup kernel against the one-frame kernel: tests/test_gpu_round4.py, without environment switches)

@@ -1,0 +1,237 @@
+"""GPU parity, round 4: NaN / inf semantics of the waterfall cells and of the within-block fold (np.max / np.min /
+np.clip as the reference applies them, K:141-143, K:195, K:100-101, K:110-111), the product library without its
+experiment switches, the eight-way quickFullScan golden, engines placed on distinct devices where a node offers them.
+All through the C ABI; tolerances as test_gpu_parity.py."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ksa_oracle as orc
+from conftest import golden, load_pkg, ROOT
+from test_gpu_parity import assert_db, assert_lin, GAIN
+from test_gpu_round2 import _regen_iq, _scan_engine, _check_sampled, _bench
+
+pytestmark = pytest.mark.gpu
+CURVES = ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def _same_specials(got, want, what):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), what + ": NaN pattern"
+    assert np.array_equal(np.isposinf(got), np.isposinf(want)), what + ": +inf pattern"
+    assert np.array_equal(np.isneginf(got), np.isneginf(want)), what + ": -inf pattern"
+    fin = np.isfinite(want)
+    if fin.any():
+        assert np.max(np.abs(got[fin] - want[fin])) < 5e-3, what + ": finite cells"
+
+
+# ------------------------------------------------------------------------------- waterfall cells: np.max (K:195, K:480)
+@pytest.mark.parametrize("n,xres,full", [(4096, 512, 32768), (512, 512, 4096), (1024, 512, 8192), (64, 16, 512),
+                                         (4096, 8, 32768), (16384, 16, 32768), (8192, 512, 16384), (65536, 512, 131072),
+                                         (65536, 32, 131072)])
+def test_waterfall_nan_cells_same_in_every_batch_shape(ksa, torch_cuda, n, xres, full):
+    """VERDICT r03 item 2.  A baseline saved from a run that saw a zero magnitude holds -inf (K:469 keeps it); a later
+    all-zero frame then gives -inf - (-inf) = NaN at those bins (K:405) and np.max (K:195) makes the whole waterfall cell
+    NaN; a normal frame gives +inf there.  Every cell-reduction path of the device -- the shuffle tree of finish_frame
+    (g = 4 .. 256), its g = 1 / g = 2 forms, its LDS path (g > 256), rowmax_batch behind the window-split mode,
+    dif16_finish_kernel -- must give the same row for the same frame whether it arrives in a batch of 3 (window-split)
+    or among many (persistent kernel), equal to the oracle's."""
+    torch = torch_cuda
+    q, frames_big = 0.5, 600 if n <= 16384 else 40
+    rng = np.random.default_rng(n + xres)
+    adj = rng.normal(-40.0, 3.0, n)
+    hole = rng.choice(n, size=max(3, n // 97), replace=False)
+    adj[hole] = -np.inf
+    distinct = 5
+    x = orc.synth_iq(full * distinct, 77 + n).astype(np.complex64).reshape(distinct, full)
+    x[2] = 0                                                    # the all-zero frame
+    win = orc.window_table("hanning", n)
+    # oracle rows of the distinct frames (a frame's row does not depend on its neighbours)
+    want = np.stack([orc.plotcompress(orc.log_no_gain(orc.curscan(x[f], n, q, win, "AVG"), GAIN) - adj, orc.heatmap_width(n, xres), "MAX")
+                     for f in range(distinct)])
+    assert np.isnan(want[2]).any() and np.isposinf(want[0]).any()
+    for frames in (3, frames_big):
+        idx = np.arange(frames) % distinct
+        dev = torch.view_as_real(torch.from_numpy(x[idx])).cuda()
+        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning", gain=GAIN, xres=xres, max_frames=frames)
+        eng.set_adj(adj, scan=False)
+        rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
+        eng.frames_dev(dev, ksa.FMT_C64, frames, hm_rows=rows)
+        got = rows.cpu().numpy()
+        for f in range(frames):
+            _same_specials(got[f], want[idx[f]], "N=%d W=%d batch of %d, frame %d" % (n, xres, frames, f))
+        st = eng.state()
+        last = min(frames, 128)
+        for f in range(frames - last, frames):                  # the ring holds the same rows
+            _same_specials(st["fftHM"][f % 128], want[idx[f]], "ring row of frame %d" % f)
+        eng.close()
+
+
+def test_waterfall_nan_against_zerospan_state(ksa, torch_cuda):
+    """The same through the frame-by-frame host entry point (ksa_frame_c64) against orc.ZeroSpanState: curves + ring."""
+    n, full, xres = 4096, 32768, 512
+    rng = np.random.default_rng(5)
+    adj = rng.normal(-40.0, 3.0, n)
+    adj[rng.choice(n, 40, replace=False)] = -np.inf
+    x = orc.synth_iq(full * 4, 99).astype(np.complex64).reshape(4, full)
+    x[1] = 0
+    win = orc.window_table("hanning", n)
+    ref = orc.ZeroSpanState(n, xres, GAIN, adj=adj)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=xres, max_frames=1)
+    eng.set_adj(adj, scan=False)
+    for f in range(4):
+        ref.push(orc.curscan(x[f], n, 0.5, win, "AVG"))
+        eng.frame(x[f])
+    st = eng.state()
+    for f in range(4):
+        _same_specials(st["fftHM"][f], ref.hm[f], "ring row %d" % f)
+    for k, w in zip(CURVES, (ref.cur, ref.max, ref.min, ref.avg)):
+        assert np.array_equal(np.isnan(st[k]), np.isnan(w)) and np.array_equal(np.isneginf(st[k]), np.isneginf(w)), k
+    eng.close()
+
+
+# ------------------------------------------------------------------------------- within-block fold: np.max / np.min (K:141-143)
+@pytest.mark.parametrize("n,q,full,frames", [(64, 0.1, 512, 5), (256, 0.5, 2048, 400), (1024, 0.5, 8192, 3), (1024, 0.5, 8192, 2100),
+                                             (4096, 0.25, 32768, 3), (4096, 0.5, 32768, 800), (8192, 0.5, 32768, 3),
+                                             (16384, 0.1, 65536, 300), (65536, 0.5, 131072, 4)])
+@pytest.mark.parametrize("mode", ["MAX", "MIN", "AVG"])
+def test_fold_propagates_nan_windows(ksa, torch_cuda, n, q, full, frames, mode):
+    """One sample of a frame is NaN -- in frame 1 inside the FIRST window only (the clean windows after it must not wash
+    it out), in frame 3 inside the LAST window only: numpy.fft turns a window that covers it into NaN and np.max / np.min
+    (K:141-143) keep the bin NaN through the rest of the block's fold.  v_max_f32 / v_min_f32 return the other operand;
+    every fold path -- slots of small transforms, the window-split shares, the pair kernel (N = 1024, large batch), the
+    32-point kernel, the second stage of the large transform -- must give the oracle's NaN pattern (other frames stay clean)."""
+    torch = torch_cuda
+    distinct = 4
+    x = orc.synth_iq(full * distinct, 1000 + n).astype(np.complex64).reshape(distinct, full)
+    x[1, 2] = np.nan
+    x[3, full - 1] = np.nan
+    idx = np.arange(frames) % distinct
+    dev = torch.view_as_real(torch.from_numpy(x[idx])).cuda()
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hamming", cumu_mode=mode, gain=GAIN, xres=64, max_frames=frames)
+    out = torch.empty((frames, n), dtype=torch.float32, device="cuda")
+    eng.curscan_dev(dev, ksa.FMT_C64, frames, out, out_mode=ksa.OUT_LINEAR)
+    got = out.cpu().numpy()
+    win = orc.window_table("hamming", n)
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = [orc.curscan(x[f], n, q, win, mode) for f in range(distinct)]
+    assert np.isnan(want[1]).any() and np.isnan(want[3]).any() and not np.isnan(want[0]).any()
+    for f in range(frames):
+        w = want[idx[f]]
+        assert np.array_equal(np.isnan(got[f]), np.isnan(w)), "N=%d %s frame %d of %d: NaN pattern" % (n, mode, f, frames)
+        ok = ~np.isnan(w)
+        if ok.any():
+            assert_lin(got[f][ok], w[ok], what="N=%d %s frame %d" % (n, mode, f))
+    eng.close()
+
+
+# ------------------------------------------------------------------------------- scan: Clip2MinAmp + LogNoGain(infTo = 0)
+def test_scan_with_zero_min_amp_maps_inf_to_zero(ksa, torch_cuda):
+    """minAmp4Clip = 0 (a legal CLI value): np.clip leaves a zero magnitude alone, 10 log10 gives -inf and the scan's
+    LogNoGain replaces +-inf by 0 (infTo = 0: K:641 -> K:110-111; the curves also START at 0 dB then, K:603-604)."""
+    torch = torch_cuda
+    n, full, fs = 256, 2048, 2.4e6
+    start, end = 100e6, 100e6 + 3 * fs
+    ref = orc.ScanState(n, start, end, fs, GAIN, 0.0, 64, 0.5)
+    steps = len(ref.centers)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=0.0, xres=64,
+                             max_frames=steps, scan_total_entries=3 * n, scan_non_overlap=0.5)
+    st = eng.scan_state()
+    assert np.all(st["Fft.Cur"] == 0.0) and np.all(st["Fft.Max"] == 0.0) and np.all(st["Fft.Avg"] == 0.0)
+    win = orc.window_table("hanning", n)
+    x = orc.synth_iq(full * steps * 2, 31).astype(np.complex64).reshape(2, steps, full)
+    x[0, 2] = 0                                                 # a silent band: zero magnitudes
+    x[1, 0] = 0
+    for p in range(2):
+        ref.run_pass([orc.curscan(x[p, s], n, 0.5, win, "AVG") for s in range(steps)])
+        eng.scan_pass(x[p])
+    st = eng.scan_state()
+    for k, w in zip(CURVES, (ref.cur, ref.max, ref.min, ref.avg)):
+        assert np.all(np.isfinite(st[k])), k
+        assert np.array_equal(st[k] == 0.0, w == 0.0), k + ": bins the reference zeroes"
+        assert_db(st[k], w, what="min_amp 0 " + k)
+    assert_db(st["fftHM"][:2], ref.hm[:2], what="min_amp 0 waterfall")
+    eng.close()
+
+
+# ------------------------------------------------------------------------------- two frames per workgroup (N = 1024)
+@pytest.mark.parametrize("q,fmt,mode", [(0.5, "c64", "AVG"), (0.1, "u8", "MAX"), (0.25, "c64", "MIN")])
+def test_pair_kernel_matches_single_frame_kernel(ksa, torch_cuda, q, fmt, mode):
+    """spectrum_pair_kernel (N = 1024, batches of >= 2 x CUs x workgroups-per-CU frames) against spectrum_kernel (the
+    same frames handed over in batches below the switch-over), with no environment switch: the product library reads
+    none.  Frames, state and waterfall rows agree to fp32 rounding (the pair kernel builds its last-pass twiddles from 6
+    instead of 15 table entries); a few frames are checked against the oracle as well."""
+    torch = torch_cuda
+    n, full = 1024, 8192
+    frames = 2 * 256 * 2 + 513                       # above the switch-over, odd
+    distinct = 37
+    x = orc.synth_iq(full * distinct, 4321 + n).astype(np.complex64).reshape(distinct, full)
+    idx = np.arange(frames) % distinct
+    if fmt == "u8":
+        dev = torch.from_numpy(orc.quantize_u8((x * 0.7).reshape(-1)).reshape(distinct, 2 * full)[idx]).cuda()
+        code = ksa.FMT_U8
+    else:
+        dev = torch.view_as_real(torch.from_numpy(x[idx])).cuda()
+        code = ksa.FMT_C64
+    outs = []
+    for chunk in (frames, 500):
+        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="kaiser", cumu_mode=mode, xres=256, max_frames=frames)
+        assert eng.kernel_info()["path"] == 4
+        db = torch.empty((frames, n), dtype=torch.float32, device="cuda")
+        rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
+        for f0 in range(0, frames, chunk):
+            cf = min(chunk, frames - f0)
+            eng.frames_dev(dev[f0:f0 + cf], code, cf, cur_db=db[f0:f0 + cf], hm_rows=rows[f0:f0 + cf])
+        st = eng.state()
+        outs.append((db.cpu().numpy(), rows.cpu().numpy(), st))
+        eng.close()
+    (da, ra, sa), (db_, rb, sb) = outs
+    assert_lin(10 ** (da / 10), 10 ** (db_.astype(np.float64) / 10), tol=2e-6, what="pair vs single frames")
+    assert not np.array_equal(da, db_), "both runs took the same kernel: the switch-over moved?"
+    top = np.max(db_, axis=1, keepdims=True)
+    strong = db_ > top - 30
+    assert np.max(np.abs(da[strong] - db_[strong])) < 1e-3
+    assert np.max(np.abs(ra - rb)) < 1e-3                       # waterfall rows = per-cell maxima
+    for k in CURVES:
+        assert_db(sa[k], sb[k], what="pair vs single " + k)
+    assert np.max(np.abs(sa["fftHM"] - sb["fftHM"])) < 1e-3 and sa["hm_index"] == sb["hm_index"]
+    win = orc.window_table("kaiser", n)
+    for f in (0, 1, frames - 1):
+        src = x[idx[f]] if fmt == "c64" else orc.unpack_u8(orc.quantize_u8(x[idx[f]] * 0.7))
+        want = orc.log_no_gain(orc.curscan(src, n, q, win, mode), 19.1)
+        assert_db(da[f], want, what="pair frame %d" % f)
+
+
+def test_library_reads_no_environment_switch(ksa, torch_cuda):
+    """a stray experiment variable must not change which kernel a user runs.  With every former
+    switch set, an engine reports the same plan as without, and the product library has no getenv import at all."""
+    torch = torch_cuda
+    base = {}
+    for n in (1024, 4096, 16384):
+        eng = ksa.SpectrumEngine(n, full_size=8 * n, non_overlap=0.5, window="hanning", max_frames=4)
+        base[n] = eng.kernel_info()
+        eng.close()
+    code = ("import importlib, json, sys; sys.path.insert(0, %r); ksa = importlib.import_module('prgs-sdr-kspecanal_amd'); out = {}\n"
+            "for n in (1024, 4096, 16384):\n"
+            "    e = ksa.SpectrumEngine(n, full_size=8 * n, non_overlap=0.5, window='hanning', max_frames=4); out[n] = e.kernel_info(); e.close()\n"
+            "print(json.dumps(out))") % ROOT
+    env = dict(os.environ, KSA_NO_PAIR="1", KSA_PAIR_ALL="1", KSA_PLAN16="1", KSA_NO_REUSE="1", KSA_NO_SPLIT="1", KSA_GRID="7",
+               KSA_LDS_PAD_KB="40", KSA_FS_SCRATCH_MB="64", KSA_LIB="/nonexistent/libksa.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = {int(k): v for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
+    assert got == base
+    nm = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "prgs-sdr-kspecanal_amd", "libksa.so")],
+                        capture_output=True, text=True)
+    assert nm.returncode == 0 and "getenv" not in nm.stdout

@@ -139,7 +139,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
     for name in declared:
         assert hasattr(pkg.lib, name)
-    assert pkg.lib.ksa_abi_version() == 2
+    assert pkg.lib.ksa_abi_version() == 3
     # without a GPU the library must fail loudly, not fall back
     import torch
     if not torch.cuda.is_available():

@@ -17,4 +17,4 @@ for _ in range(2): eng.curscan_dev(iq, ksa.FMT_C64, frames, out, out_mode=ksa.OU
 torch.cuda.synchronize(); eng.prof_enable(True)
 for _ in range(5): eng.curscan_dev(iq, ksa.FMT_C64, frames, out, out_mode=ksa.OUT_DB)
 ms, k = eng.prof_read()
-print("%s N=%d q=%s: %.3f ms  %.2f MFFT/s  vgpr %d" % (os.environ.get("KSA_LIB", "default").split("_")[-1], n, q, ms / k, frames * eng.num_windows / (ms / k) / 1e3, eng.kernel_info()["vgprs"]))
+print("%s N=%d q=%s: %.3f ms  %.2f MFFT/s  vgpr %d" % (os.environ.get("KSA_VARIANT", "main"), n, q, ms / k, frames * eng.num_windows / (ms / k) / 1e3, eng.kernel_info()["vgprs"]))

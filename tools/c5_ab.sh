@@ -3,8 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 for lib in "$@"; do
-  if [ "$lib" = main ]; then unset KSA_LIB; else export KSA_LIB=$R/$lib; fi
-  timeout -k 10 200 python3 bench.py --config ${CFG:-5} --steps 10 --warmup 2 --no-cpu > /tmp/ab.json 2> /tmp/ab.err || { echo "$lib failed"; tail -3 /tmp/ab.err; continue; }
+  tools/with_lib.sh $lib timeout -k 10 200 python3 bench.py --config ${CFG:-5} --steps 10 --warmup 2 --no-cpu > /tmp/ab.json 2> /tmp/ab.err || { echo "$lib failed"; tail -3 /tmp/ab.err; continue; }
   python3 -c "
 import json
 d=json.load(open('/tmp/ab.json'))

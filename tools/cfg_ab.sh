@@ -4,8 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 for rep in 1 2; do
 for lib in "$@"; do
-  if [ "$lib" = main ]; then unset KSA_LIB; else export KSA_LIB=$R/$lib; fi
-  timeout -k 10 200 python3 bench.py --config ${CFG:-2} --steps 20 --warmup 3 --no-cpu $BENCH_ARGS > /tmp/ab.json 2> /tmp/ab.err || { echo "$lib failed"; tail -3 /tmp/ab.err; continue; }
+  tools/with_lib.sh $lib timeout -k 10 200 python3 bench.py --config ${CFG:-2} --steps 20 --warmup 3 --no-cpu $BENCH_ARGS > /tmp/ab.json 2> /tmp/ab.err || { echo "$lib failed"; tail -3 /tmp/ab.err; continue; }
   python3 -c "
 import json
 d=json.load(open('/tmp/ab.json'))

@@ -6,8 +6,8 @@ cd "$(dirname "$0")/.."
 for n in 16 32 64 128 256 512 1024 2048 4096 8192 16384; do
   for q in 0.5 0.25 0.1; do
     fr=$((16777216 / n))
-    a=$(KSA_LIB=variants/libksa_foldconst.so timeout -k 10 120 python tools/bench_one.py $n $q hanning $((n*8)) $fr | awk '{print $4}')
-    b=$(KSA_LIB=variants/libksa_foldgen.so timeout -k 10 120 python tools/bench_one.py $n $q hanning $((n*8)) $fr | awk '{print $4}')
+    a=$(tools/with_lib.sh variants/libksa_foldconst.so timeout -k 10 120 python tools/bench_one.py $n $q hanning $((n*8)) $fr | awk '{print $4}')
+    b=$(tools/with_lib.sh variants/libksa_foldgen.so timeout -k 10 120 python tools/bench_one.py $n $q hanning $((n*8)) $fr | awk '{print $4}')
     echo "N=$n q=$q constant $a ms run-time branch $b ms"
   done
 done
