@@ -18,6 +18,12 @@ RCCL all-gather per step carries what the ranks must share (distributed.py): the
 GPU brings its own time chunk), the scan configs strongly (one fixed range split over the GPUs; halo exchange between
 neighbours + one all-gather of the partial waterfall rows).
 
+N > 1 lines prove their own topology: `ranks` (backend, world size, RCCL version and per rank host / device ordinal /
+PCI bus id / uuid, gathered from the ranks themselves), `state_identical_across_ranks` (sha256 of every rank's
+Cur/Max/Min/Avg + waterfall ring after the timed region) and, for the zeroSpan configs, a `strong` sub-record (the
+1-GPU batch split over the ranks) next to the weak headline.  `--inprocess` times the torch-free form instead: ONE process,
+one engine per visible GPU, merged by ksa_allreduce_state / ksa_scan_allstitch (peer copies, no RCCL).
+
 Launch: under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plainly as
 `python bench.py --gpus N`: the parent then starts N fresh rank processes itself (before it has touched the GPU),
 relays rank 0's JSON line and fails if any rank fails.  Rank 0 prints ONE JSON line on stdout.
@@ -143,9 +149,10 @@ def cpu_baseline(cfg, nwin, seconds=3.0, rounds=5):
 
 
 def cpu_baseline_multicore(config_id, nwin, seconds=3.0, rounds=5, max_workers=16):
-    """the same port on independent units, one plain child process per usable core -- capped at 16,
-    the CPU share (and process budget) a one-GPU box grants -- the non-target multi-core figure.  Children never
-    touch the GPU; any failure or timeout just drops the figure."""
+    """the same port on independent units, one plain child process per usable core -- capped at
+    --cpu-workers (default 16: the CPU share and process budget a one-GPU box grants; `--cpu-workers 256` on a box that
+    allows it gives the all-cores figure) -- the non-target multi-core figure.  Children never touch the GPU; any
+    failure or timeout just drops the figure."""
     workers = max(1, min(max_workers, len(os.sched_getaffinity(0))))
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(config_id), str(seconds),
@@ -163,8 +170,8 @@ def cpu_baseline_multicore(config_id, nwin, seconds=3.0, rounds=5, max_workers=1
         return None
     rates = sorted(sum(w[r][0] for w in per_worker) * nwin / max(w[r][1] for w in per_worker) for r in range(rounds))
     return {"value": rates[len(rates) // 2], "unit": "FFT/s", "cores": workers, "kind": "port",
-            "sample": "median of %d runs of >= %.1f s over %d processes (of %d usable cores; capped at 16 = the CPU share and process budget of a one-GPU box, a stated deviation from SURVEY 8d's 'all usable cores'), numpy float64"
-                      % (rounds, seconds, workers, len(os.sched_getaffinity(0)))}
+            "sample": "median of %d runs of >= %.1f s over %d processes (of %d usable cores; --cpu-workers %d: the default 16 is the CPU share and process budget of a one-GPU box, a stated deviation from SURVEY 8d's 'all usable cores'), numpy float64"
+                      % (rounds, seconds, workers, len(os.sched_getaffinity(0)), max_workers)}
 
 
 # ------------------------------------------------------------------------------------------- self launch
@@ -211,16 +218,26 @@ def spawn_ranks(n):
     sys.stdout.flush()
 
 
-def secondary_configs(fmt):
+SECONDARY_BUDGET_S = 150.0      # all side runs together; the driver's limit for the whole bench is 600 s
+
+
+def secondary_configs(fmt, budget_s=SECONDARY_BUDGET_S):
     """The other BASELINE configurations (C3 fmScan, C4 quickFullScan shape, C5 fftSize 65536 at 75 % overlap) as
     short runs in child processes after the headline's timed region, so that the record the driver keeps carries a
     driver-run number for each of them too: {config: {value, unit, ms_per_step, roofline fractions} | {error}}.  The
-    headline's own fields are untouched; `python bench.py --config K` gives the full line of configuration K."""
+    headline's own fields are untouched; `python bench.py --config K` gives the full line of configuration K.  The side
+    runs share ONE deadline (a slow or hung one costs the others, never the headline line: what is left when it expires
+    is recorded as skipped)."""
     res = {}
+    t_end = time.monotonic() + budget_s
     for k in (3, 4, 5):
+        left = t_end - time.monotonic()
+        if left < 15.0:
+            res[str(k)] = {"skipped": "side-run budget of %.0f s used up" % budget_s}
+            continue
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(k), "--fmt", fmt, "--steps", "10",
-                                "--warmup", "2", "--no-cpu", "--no-secondary"], capture_output=True, text=True, timeout=240)
+                                "--warmup", "2", "--no-cpu", "--no-secondary"], capture_output=True, text=True, timeout=left)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:
                 res[str(k)] = {"error": (r.stderr or "no output")[-300:]}
@@ -229,8 +246,10 @@ def secondary_configs(fmt):
             rf = d["roofline"]
             res[str(k)] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                            "msamples_per_s": d["msamples_per_s"], "steps": d["steps"], "kernel": rf["kernel"],
-                           "avg_kernel_ms": rf["avg_kernel_ms"], "frac": rf["frac"], "frac_step": rf["frac_step"],
-                           "flop_frac": rf["flop_frac"], "traffic": rf["traffic"]}
+                           "avg_kernel_ms": rf["avg_kernel_ms"], "bound": rf["bound"], "limiter": rf["limiter"],
+                           "frac": rf["frac"], "frac_step": rf["frac_step"], "flop_frac": rf["flop_frac"],
+                           "lds_frac": rf["lds_frac"], "valu_issue_frac": rf["valu_issue_frac"],
+                           "traffic": rf["traffic"], "traffic_over_algorithmic": rf["traffic_over_algorithmic"]}
         except Exception as ex:      # a failing side run must never take the headline line with it
             res[str(k)] = {"error": repr(ex)[:300]}
     return res
@@ -246,20 +265,75 @@ def csrc_sha256():
     return h.hexdigest()
 
 
-def pmc_traffic(key):
+def pmc_record(key):
+    """Counter figures of the separate rocprofv3 --pmc passes (tools/profile_bench.sh -> tools/summarize_profile.py) for
+    this bench configuration, or {} when they were taken on other kernel sources."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         rec = json.load(open(path))
         ent = rec.get("entries", {}).get(key)
         if ent and ent.get("csrc_sha256") == csrc_sha256():
-            return ent["hbm_bytes_per_launch"], ent.get("source")
+            return ent
     except Exception:
         pass
-    return None, None
+    return {}
+
+
+# What binds each configuration, as the counters of profiles/r0N_c*_pmc.json show it (DESIGN.md 4.5): `bound` names the
+# resource, `limiter` says it in a sentence.  The north star prices every configuration against HBM (`frac`); the fp32
+# (`flop_frac`), VALU-issue and LDS-array fractions stand beside it.
+BOUND = {
+    2: ("hbm", "priced against HBM as the north star asks (traffic = 1.00x algorithmic); what actually limits it is VALU issue "
+               "(~0.43 of the issue slots) and the LDS exchange (~0.45 of the LDS-array cycles) running in series at 3 waves per SIMD"),
+    3: ("valu", "90 % window overlap: every sample is transformed ten times, VALU alone is 4.9 of 8.0 us per window at one workgroup "
+                "(135 KB of LDS) per CU; HBM sees 0.06 of its peak"),
+    4: ("valu", "90 % window overlap at N = 64: 16 transforms per wave, VALU-issue bound (no pipe above 40 %); HBM sees 0.13 of its peak"),
+    5: ("hbm (Z round trip)", "two streaming passes over the first-stage scratch Z: 7.9x the algorithmic bytes move, both stages run at the "
+                              "4.7-5.0 TB/s a mixed read/write stream reaches"),
+}
+
+
+# ------------------------------------------------------------------------------------------- topology / state proofs
+def device_identity(torch, local):
+    """What tells two GPUs apart: ordinal, marketing name, PCI bus id and uuid (whatever this torch build exposes)."""
+    pr = torch.cuda.get_device_properties(local)
+    ident = {"device": int(local), "name": pr.name, "host": socket.gethostname(), "pid": os.getpid()}
+    for attr in ("pci_bus_id", "pci_device_id", "pci_domain_id", "uuid", "gcnArchName"):
+        v = getattr(pr, attr, None)
+        if v is not None:
+            ident[attr] = str(v)
+    return ident
+
+
+def rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as ex:
+        return "unavailable (%s)" % type(ex).__name__
+
+
+def state_digest(st):
+    """sha256 over Cur / Max / Min / Avg + the waterfall ring + its position: equal digests = the same bits."""
+    h = hashlib.sha256()
+    for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg", "fftHM"):
+        h.update(np.ascontiguousarray(st[k], dtype=np.float64).tobytes())
+    h.update(str(int(st["hm_index"])).encode())
+    return h.hexdigest()
+
+
+def ranks_block(torch, dist, backend, world, local):
+    """Every rank reports itself; rank 0 receives the list.  `distinct_devices` counts (host, bus id / uuid / ordinal)."""
+    mine = dict(device_identity(torch, local), rank=dist.get_rank(), local_rank=int(os.environ.get("LOCAL_RANK", "0")))
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    key = lambda r: (r["host"], r.get("uuid") or r.get("pci_bus_id") or r["device"])
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": rccl_version(torch) if backend == "nccl" else None,
+            "distinct_devices": len({key(r) for r in every}), "visible_devices_rank0": torch.cuda.device_count(), "per_rank": every}
 
 
 # ------------------------------------------------------------------------------------------- the bench
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -270,12 +344,65 @@ def main():
     ap.add_argument("--fmt", choices=("c64", "u8"), default="c64")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="length of each of the 5 CPU measurements")
+    ap.add_argument("--cpu-workers", type=int, default=16,
+                    help="processes of the multi-core CPU figure (capped by the usable cores; 16 = the CPU share of a one-GPU box)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline run on one GPU: skip the short runs of the other BASELINE configurations (3, 4, 5)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1, zeroSpan only: run the multi-GPU merge path on a one-rank group, to price its fixed cost")
-    args = ap.parse_args()
+    ap.add_argument("--inprocess", action="store_true",
+                    help="ONE process, --gpus engines placed on the visible devices (engine r on device r %% device_count), merged by "
+                         "ksa_allreduce_state / ksa_scan_allstitch: the torch-free multi-GPU form (no RCCL)")
+    return ap.parse_args()
 
+
+def roofline_block(cfg, args, eng, units_per_step, kern_ms, launches, step_s):
+    """algorithmic bytes over the spectrum stage's HIP-event time, with the fp32 / LDS / VALU-issue fractions
+    and the counter traffic of the stored rocprofv3 passes beside it."""
+    n, nwin = cfg["n"], eng.num_windows
+    sb = 8 if args.fmt == "c64" else 2
+    info = eng.kernel_info()
+    bpu = algorithmic_bytes(cfg, sb, nwin)
+    avg_kernel_s = kern_ms / 1e3 / max(1, launches)
+    alg_bytes = units_per_step * bpu
+    achieved = alg_bytes / avg_kernel_s / 1e9
+    tflops = units_per_step * nwin * algorithmic_flops_per_fft(n) / avg_kernel_s / 1e12
+    if info["path"] == 2:
+        kernel = "ksa::dif16_kernel<%s> + ksa::spectrum_kernel<%d,c64> + ksa::dif16_finish_kernel (N = 16*%d)" % (args.fmt, n // 16, n // 16)
+    elif info["path"] == 4:
+        kernel = "ksa::spectrum_pair_kernel<%d,%s> (two frames per workgroup, packed fp32)" % (n, args.fmt)
+    elif info["path"] == 3:
+        kernel = "ksa::spectrum32_kernel<%d,%s>" % (n, args.fmt)
+    else:
+        kernel = "ksa::spectrum_kernel<%d,%s>" % (n, args.fmt)
+    rec = pmc_record("%d:%s:%d" % (args.config, args.fmt, units_per_step))
+    traffic = rec.get("hbm_bytes_per_launch")
+    bound, limiter = BOUND[args.config]
+    return {"bound": bound, "limiter": limiter, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": rec.get("source"),
+            "traffic_note": ("counter figures (traffic = 2*FETCH_SIZE + WRITE_SIZE per step; lds_frac = SQ_LDS_IDX_ACTIVE / CUs / kernel cycles; "
+                             "valu_issue_frac = SQ_INSTS_VALU * 2 clk / SIMDs / kernel cycles; lds_conflict_ratio = SQ_LDS_BANK_CONFLICT / "
+                             "SQ_LDS_IDX_ACTIVE) come from the separate rocprofv3 --pmc passes stored in profiles/pmc_traffic.json for this "
+                             "exact kernel source (sha256-checked); NOT measured by this run") if rec else None,
+            # counter traffic (L2 <-> fabric; Infinity-Cache hits included) per step over the stage's time
+            "traffic_gbs": (traffic / avg_kernel_s / 1e9) if traffic else None,
+            "traffic_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+            "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_unit": bpu,
+            # the whole step (spectrum stage + accumulate/stitch + collective) against the same bytes
+            "frac_step": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+            # what the chip is busy with: fp32 vector fraction (live), LDS-array and VALU-issue fractions (stored counters)
+            "tflops": tflops, "flop_peak": FP32_PEAK_TFLOPS, "flop_frac": tflops / FP32_PEAK_TFLOPS,
+            "lds_frac": rec.get("lds_frac"), "lds_conflict_ratio": rec.get("lds_conflict_ratio"),
+            "valu_issue_frac": rec.get("valu_issue_frac"), "shader_clock_ghz": rec.get("shader_clock_ghz"),
+            "threads": info["threads"], "lds_bytes": info["lds_bytes"], "vgprs": info["vgprs"], "grid": info["grid"]}
+
+
+def main():
+    args = parse_args()
+    if args.inprocess:
+        return main_inprocess(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
 
@@ -312,22 +439,11 @@ def main():
         dist.init_process_group(backend, rank=0, world_size=1, device_id=torch.device("cuda", local) if backend == "nccl" else None)
 
     n, full, q = cfg["n"], cfg["full"], cfg["q"]
-    sb = 8 if args.fmt == "c64" else 2
     fmt = ksa.FMT_C64 if args.fmt == "c64" else ksa.FMT_U8
     stream = torch.cuda.current_stream().cuda_stream
+    resident_iq = lambda units: make_resident_iq(torch, orc, args, cfg, units, rank)
 
-    def resident_iq(units):
-        """`units` capture blocks in HBM, tiled from <= 64 MiB of distinct host-generated blocks (content does not
-        affect timing; H2D is outside the timed region)."""
-        distinct = max(1, min(units, 256, (64 << 20) // (full * 8)))
-        host = orc.synth_iq(full * distinct, 20201226 + args.config + rank).astype(np.complex64)
-        if args.fmt == "c64":
-            tile = torch.view_as_real(torch.from_numpy(host)).reshape(distinct, full, 2).cuda()
-        else:
-            tile = torch.from_numpy(orc.quantize_u8(host * 0.8)).reshape(distinct, full * 2).cuda()
-        reps = (units + distinct - 1) // distinct
-        return tile.repeat(reps, *([1] * (tile.dim() - 1)))[:units].contiguous()
-
+    strong_step = None
     if cfg["mode"] == "zerospan":
         frames = args.frames or cfg["frames"]
         units_per_step = frames                       # per rank
@@ -338,6 +454,9 @@ def main():
         hm_rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
         run = ksa_dist.ShardedZeroSpan(eng, rank, world, always_collective=args.force_collective)
         step = lambda: run.step(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
+        if world > 1 and frames // world >= 1:
+            fs = frames // world                      # the SAME job as one GPU's step, split over the ranks
+            strong_step = (fs, lambda: run.step(iq, fmt, fs, cur_db=cur_db, hm_rows=hm_rows))
         sharding = "time-chunk"
         collective = ("RCCL: 1 all-gather of [4N + 128W] floats per rank per step over %d ranks, merged by ksa_merge_gathered_dev"
                       % world) if world > 1 else "none"
@@ -370,24 +489,48 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(fn, steps_):
+        """EXACTLY steps_ steps between two barrier + synchronize fences; the slowest rank's time."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps_):
+            fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for _ in range(args.warmup):
         step()
     fence()
     if cfg["mode"] == "scan":
         coll_bytes = run.collective_bytes() if world > 1 else {}
     eng.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt = timed(step, args.steps)
     kern_ms, launches = eng.prof_read()
     eng.prof_enable(False)
 
+    # ---- after the timed region: does every rank hold the same result?  (scan: after assembling the sharded curves)
+    proof = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        st = run.gather_state(steps) if cfg["mode"] == "scan" else eng.state()
+        digests = [None] * world
+        dist.all_gather_object(digests, state_digest(st))
+        proof = {"state_identical_across_ranks": len(set(digests)) == 1, "state_sha256_rank0": digests[0],
+                 "ranks_differing_from_rank0": [r for r, dg in enumerate(digests) if dg != digests[0]]}
+    strong = None
+    if strong_step is not None:
+        fs, sfn = strong_step
+        for _ in range(args.warmup):
+            sfn()
+        sdt = timed(sfn, args.steps)
+        strong = {"scaling": "strong", "what": "the one-GPU step of %d frames split over the %d ranks (%d each)" % (fs * world, world, fs),
+                  "frames_per_gpu_per_step": fs, "value": fs * world * args.steps * eng.num_windows / sdt, "unit": "FFT/s",
+                  "ms_per_step": sdt / args.steps * 1e3}
+    ranks = ranks_block(torch, dist, backend, world, local) if world > 1 else None
 
     if rank == 0:
         nwin = eng.num_windows
@@ -396,23 +539,7 @@ def main():
         else:
             units_all = (args.passes or cfg["passes"]) * steps * args.steps
         ffts_per_s = units_all * nwin / dt
-        info = eng.kernel_info()
-        bpu = algorithmic_bytes(cfg, sb, nwin)
-        avg_kernel_s = kern_ms / 1e3 / max(1, launches)
-        alg_bytes = units_per_step * bpu
-        achieved = alg_bytes / avg_kernel_s / 1e9
-        tflops = units_per_step * nwin * algorithmic_flops_per_fft(n) / avg_kernel_s / 1e12
         step_s = dt / args.steps
-        if info["path"] == 2:
-            kernel = "ksa::dif16_kernel<%s> + ksa::spectrum_kernel<%d,c64> + ksa::dif16_finish_kernel (N = 16*%d)" % (args.fmt, n // 16, n // 16)
-        elif info["path"] == 4:
-            kernel = "ksa::spectrum_pair_kernel<%d,%s> (two frames per workgroup, packed fp32)" % (n, args.fmt)
-        elif info["path"] == 3:
-            kernel = "ksa::spectrum32_kernel<%d,%s>" % (n, args.fmt)
-        else:
-            kernel = "ksa::spectrum_kernel<%d,%s>" % (n, args.fmt)
-        key = "%d:%s:%d" % (args.config, args.fmt, units_per_step)
-        traffic, traffic_src = pmc_traffic(key)
         out = {
             "metric": cfg["metric"], "value": ffts_per_s, "unit": "FFT/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": scaling,
@@ -422,25 +549,19 @@ def main():
                             "input": "complex64" if args.fmt == "c64" else "uint8", "samples_per_unit": full,
                             "windows_per_unit": nwin, "sharding": sharding, "collective": collective,
                             "collective_bytes_per_rank_per_step": coll_bytes}, **batch),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_note": ("counter bytes per step (2*FETCH_SIZE + WRITE_SIZE) from the separate rocprofv3 --pmc passes stored in "
-                                          "profiles/pmc_traffic.json for this exact kernel source (sha256-checked); NOT measured by this run") if traffic else None,
-                         # counter traffic (L2 <-> fabric; Infinity-Cache hits included) per step over the stage's time
-                         "traffic_gbs": (traffic / avg_kernel_s / 1e9) if traffic else None,
-                         "traffic_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": kernel, "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
-                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_unit": bpu,
-                         # the whole step (spectrum stage + accumulate/stitch + collective) against the same bytes
-                         "frac_step": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
-                         # at 75-90 % overlap the path is far from HBM-bound: fp32 vector fraction next to it
-                         "tflops": tflops, "flop_peak": FP32_PEAK_TFLOPS, "flop_frac": tflops / FP32_PEAK_TFLOPS,
-                         "threads": info["threads"], "lds_bytes": info["lds_bytes"], "vgprs": info["vgprs"],
-                         "grid": info["grid"]},
+            "roofline": roofline_block(cfg, args, eng, units_per_step, kern_ms, launches, step_s),
         }
+        if world > 1:
+            out["ranks"] = ranks
+            out.update(proof)
+            out["multi_gpu_note"] = ("%d rank processes over %s; %d distinct device(s) among them%s" % (
+                world, ranks["backend"], ranks["distinct_devices"],
+                "" if ranks["distinct_devices"] == world else " -- a functional REHEARSAL of the launch path on shared devices, not a scaling measurement"))
+            if strong is not None:
+                out["strong"] = strong
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, nwin, args.cpu_seconds)
-            multi = cpu_baseline_multicore(args.config, nwin, args.cpu_seconds)
+            multi = cpu_baseline_multicore(args.config, nwin, args.cpu_seconds, max_workers=args.cpu_workers)
             if multi is not None:
                 out["cpu_baseline_multicore"] = multi
         if world == 1 and args.config == 2 and not args.no_secondary and not args.force_collective:
@@ -451,6 +572,121 @@ def main():
         dist.barrier()
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def make_resident_iq(torch, orc, args, cfg, units, seed_rank, device=None):
+    """`units` capture blocks in HBM, tiled from <= 64 MiB of distinct host-generated blocks (content does not
+    affect timing; H2D is outside the timed region)."""
+    full = cfg["full"]
+    dev = "cuda" if device is None else "cuda:%d" % device
+    distinct = max(1, min(units, 256, (64 << 20) // (full * 8)))
+    host = orc.synth_iq(full * distinct, 20201226 + args.config + seed_rank).astype(np.complex64)
+    if args.fmt == "c64":
+        tile = torch.view_as_real(torch.from_numpy(host)).reshape(distinct, full, 2).to(dev)
+    else:
+        tile = torch.from_numpy(orc.quantize_u8(host * 0.8)).reshape(distinct, full * 2).to(dev)
+    reps = (units + distinct - 1) // distinct
+    return tile.repeat(reps, *([1] * (tile.dim() - 1)))[:units].contiguous()
+
+
+def main_inprocess(args):
+    """The torch-free multi-GPU form (SURVEY 8b allreduce_state(handles[], n)): ONE process drives --gpus engines, engine
+    r on device r % device_count, each on its own stream; per step every engine runs its share (no commit) and the
+    library merges them -- ksa_allreduce_state (time chunk: peer copies of the exchange blocks + merge kernel on every
+    engine) or ksa_scan_allstitch (band shard: halo peer copies, range stitch, row merge).  torch only provides the
+    resident input buffers here.  Timing: host clock around --steps steps, every engine synchronised on both sides."""
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    ksa = importlib.import_module("prgs-sdr-kspecanal_amd")
+    ksa_dist = importlib.import_module("prgs-sdr-kspecanal_amd.distributed")
+    orc = _oracle()
+    cfg = dict(CONFIGS[args.config])
+    world, ndev = args.gpus, torch.cuda.device_count()
+    n, full, q = cfg["n"], cfg["full"], cfg["q"]
+    fmt = ksa.FMT_C64 if args.fmt == "c64" else ksa.FMT_U8
+    devs = [r % ndev for r in range(world)]
+    engines, inputs, outs = [], [], []
+    if cfg["mode"] == "zerospan":
+        frames = args.frames or cfg["frames"]
+        for r, dv in enumerate(devs):
+            inputs.append(make_resident_iq(torch, orc, args, cfg, frames, r, device=dv))
+            engines.append(ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=cfg["window"], gain=GAIN, xres=cfg["xres"],
+                                              max_frames=frames, device=dv))
+        total = frames * world
+        hm = [0]
+
+        def step():
+            for r, eng in enumerate(engines):
+                eng.set_hm_index((hm[0] + r * frames) % 128)
+                eng.frames_dev(inputs[r], fmt, frames, first_index=r * frames, total_frames=total, commit=False)
+            ksa.allreduce_state(engines, frames, hm[0])
+            hm[0] = (hm[0] + total) % 128
+        units_all_per_step, merge = frames * world, "ksa_allreduce_state"
+        batch = {"frames_per_gpu_per_step": frames}
+        scaling = "weak"
+    else:
+        passes = args.passes or cfg["passes"]
+        end, steps, total = scan_geometry(cfg)
+        for r, dv in enumerate(devs):
+            lo, hi = ksa_dist.step_range(steps, r, world)
+            mine = hi - lo
+            inputs.append(make_resident_iq(torch, orc, args, cfg, max(1, passes * mine), r, device=dv))
+            engines.append(ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=cfg["window"], gain=GAIN, xres=cfg["xres"],
+                                              max_frames=max(1, passes * mine), device=dv, scan_total_entries=total, scan_non_overlap=0.5))
+            outs.append(torch.empty((passes, max(mine, 1), n), dtype=torch.float32, device="cuda:%d" % dv))
+
+        def step():
+            for r, eng in enumerate(engines):
+                lo, hi = ksa_dist.step_range(steps, r, world)
+                if hi > lo:
+                    eng.scan_spectra_dev(inputs[r], fmt, passes * (hi - lo), outs[r])
+            ksa.scan_allstitch(engines, [outs[r] if ksa_dist.step_range(steps, r, world)[1] > ksa_dist.step_range(steps, r, world)[0] else None
+                                         for r in range(world)], steps, passes)
+        units_all_per_step, merge = passes * steps, "ksa_scan_allstitch"
+        batch = {"passes_per_step": passes, "steps_per_pass": steps, "total_entries": total}
+        scaling = "strong"
+
+    def sync_all():
+        for eng in engines:
+            eng.synchronize()
+
+    for dv in set(devs):
+        torch.cuda.synchronize(dv)
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if cfg["mode"] == "zerospan":
+        digests = [state_digest(eng.state()) for eng in engines]
+    else:
+        curves = ksa.scan_gather_state(engines, steps)
+        digests = []
+        for eng in engines:
+            st = eng.scan_state()
+            digests.append(state_digest(dict(curves, fftHM=st["fftHM"], hm_index=st["hm_index"])))
+    nwin = engines[0].num_windows
+    idents = [dict(device_identity(torch, dv), engine=r) for r, dv in enumerate(devs)]
+    distinct = len(set(devs))
+    out = {"metric": cfg["metric"], "value": units_all_per_step * args.steps * nwin / dt, "unit": "FFT/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "msamples_per_s": units_all_per_step * args.steps * full / dt / 1e6,
+           "config": dict({"workload": cfg["workload"], "baseline_config": args.config, "input": "complex64" if args.fmt == "c64" else "uint8",
+                           "driver": "inprocess: one process, %d engines, merged by %s (peer copies, no RCCL)" % (world, merge)}, **batch),
+           "ranks": {"backend": "inprocess (hipMemcpyPeerAsync + events)", "world_size": world, "rccl_version": None,
+                     "distinct_devices": distinct, "visible_devices_rank0": ndev, "per_rank": idents},
+           "state_identical_across_ranks": len(set(digests)) == 1, "state_sha256_rank0": digests[0],
+           "multi_gpu_note": "%d engines on %d distinct device(s)%s" % (
+               world, distinct, "" if distinct == world else " -- a functional REHEARSAL on shared devices, not a scaling measurement")}
+    for eng in engines:
+        eng.close()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -22,14 +22,22 @@ template <int N>
 struct PlanPair {
   using P = Plan<N>;
   static_assert(P::S == 1 && P::T <= 256 && P::M >= 2, "pair kernel: one transform per workgroup, N = 1024 .. 4096");
-  static constexpr int LDS_BYTES = P::NPAD * 16 + P::MID * 8;
-  static_assert(4 * N * 4 <= P::NPAD * 16, "output planes must fit the exchange buffer");
+  // LDS layout of the exchanges for 16-byte pair elements (ds_write_b128: 8 groups of 8 lanes over 32 banks; ds_read_b128: 4
+  // groups of 16 lanes over 64 banks): the transposed / natural scheme of Plan<N> with the row stride re-tuned for the wider
+  // element (tools/lds_layout.py: 544 instead of 720 LDS cycles per wave and pair of transforms).  N = 1024 only -- the one
+  // size the product instantiates; the experiments builds of 2048 / 4096 keep the one-pad-per-16 order.
+  static constexpr bool XLAYOUT = KSA_XLAYOUT && N == 1024;
+  static constexpr int ST1 = 260, K2 = 4, SH2 = 6;
+  static constexpr int NPAD = XLAYOUT ? 1084 : P::N_PLUS_PAD16;
+  static constexpr int LDS_BYTES = NPAD * 16 + P::MID * 8;
+  static_assert(4 * N * 4 <= NPAD * 16, "output planes must fit the exchange buffer");
 };
 
 template <int N, int FMT, int RM, int CM>
 __global__ __launch_bounds__(Plan<N>::T, 2) void spectrum_pair_kernel(const SpecParams p) {
   using P = Plan<N>;
-  constexpr int L = P::L, T = P::T, M = P::M, R0 = P::R0, B0 = P::B0, NPAD = P::NPAD;
+  using PP = PlanPair<N>;
+  constexpr int L = P::L, T = P::T, M = P::M, R0 = P::R0, B0 = P::B0, NPAD = PP::NPAD;
   constexpr int SB = FMT == FMT_C64 ? 8 : 2;
   extern __shared__ __attribute__((aligned(16))) cx2 lds2[];
   cx2* const my = lds2;
@@ -120,14 +128,27 @@ __global__ __launch_bounds__(Plan<N>::T, 2) void spectrum_pair_kernel(const Spec
       for (int b = 0; b < B0; ++b) {
         const int i = l + b * L;
 #pragma unroll
-        for (int t = 0; t < R0; ++t) my[padi(i * R0 + perm<R0>(t))] = v[b * R0 + t];
+        for (int t = 0; t < R0; ++t) {
+          if constexpr (PP::XLAYOUT) my[perm<R0>(t) * PP::ST1 + i] = v[b * R0 + t];      // exchange 1 transposed: [output][butterfly]
+          else my[padi(i * R0 + perm<R0>(t))] = v[b * R0 + t];
+        }
       }
       __syncthreads();
       int pp = R0, tw_off = 0;
 #pragma unroll
       for (int s = 1; s < M; ++s) {
+        if constexpr (!PP::XLAYOUT) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = my[padi(l + L * t)];
+          for (int t = 0; t < 16; ++t) v[t] = my[padi(l + L * t)];
+        } else if (s == 1) {
+          const cx2* const src = my + (l % R0) * PP::ST1 + l / R0;          // element l + L*t = output l % R0 of butterfly l / R0 + (L/R0)*t
+#pragma unroll
+          for (int t = 0; t < 16; ++t) v[t] = src[(L / R0) * t];
+        } else {
+          const cx2* const src = my + l;                                     // natural order, K2 pads per 2^SH2 = L elements
+#pragma unroll
+          for (int t = 0; t < 16; ++t) v[t] = src[(L + PP::K2) * t];
+        }
         if (s < M - 1) {
           const float2* tw = tw_lds + tw_off + (l & (pp - 1));
           float2 tm[15];
@@ -137,8 +158,14 @@ __global__ __launch_bounds__(Plan<N>::T, 2) void spectrum_pair_kernel(const Spec
           __syncthreads();
           const int kk = l & (pp - 1);
           const int j = (l - kk) * 16 + kk;
+          if constexpr (PP::XLAYOUT) {
+            cx2* const dst = my + j + PP::K2 * (l >> ilog2(R0));
 #pragma unroll
-          for (int t = 0; t < 16; ++t) my[padi(j + perm<16>(t) * pp)] = v[t];
+            for (int t = 0; t < 16; ++t) dst[perm<16>(t) * R0] = v[t];
+          } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) my[padi(j + perm<16>(t) * pp)] = v[t];
+          }
           __syncthreads();
           tw_off += 15 * pp;
           pp *= 16;

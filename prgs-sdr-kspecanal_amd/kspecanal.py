@@ -13,6 +13,9 @@ arrays handed to matplotlib: d['Fft.Cur'|'Fft.Max'|'Fft.Min'|'Fft.Avg'], the fre
 `device`, `iqFormat` (c64|u8).  What moved to the GPU: everything from the IQ block to those arrays.
 Deliberate differences: playback needs no SDR; in scan mode the Levels plot is
 refreshed once per pass (the whole pass is one device call) instead of once per tuned band.
+Hand-off traffic: with a decimating pltCompress (AVG|MAX|MIN) a frame / pass brings back the four
+xRes-point Levels curves, the peak markers and the ONE new waterfall row (ksa_read_view, d['handoff.bytes']); the
+full-width d['Fft.*'] arrays are read from the device when a RAW / CONV plot needs them and once at the end of a run.
 """
 import pickle
 import signal
@@ -338,7 +341,8 @@ def _adj_siglvls(d, cur):
     """K:400-411: the curves are stored raw and adjusted on the way to the plot."""
     adj = d.get("Fft.Adj")
     if d["AdjSigLvls"] != "" and adj is not None:
-        return d["Fft.Max"] - adj, d["Fft.Min"] - adj, d["Fft.Avg"] - adj, cur - adj
+        sub = lambda v: None if v is None else v - adj                      # (a curve switched off is still None, K:471-476)
+        return sub(d["Fft.Max"]), sub(d["Fft.Min"]), sub(d["Fft.Avg"]), sub(cur)
     return d["Fft.Max"], d["Fft.Min"], d["Fft.Avg"], cur
 
 
@@ -423,6 +427,75 @@ def plot_highs(d, freqs, levels, eng=None, curve=None, scan=False):
                 marked.append((float(freqs[i]), float(levels[i])))
                 if len(marked) >= count:
                     break
+    _show_highs(d, marked)
+    return marked
+
+
+def _view_on_device(d, n):
+    """The Levels curves can be decimated on the device (pltCompress AVG|MAX|MIN over whole groups, K:186-201): then
+    only xRes-sized arrays have to cross PCIe per frame / pass."""
+    return d["pltCompress"] in ("AVG", "MAX", "MIN") and n // d["xRes"] > 0 and n % d["xRes"] == 0
+
+
+def _materialize(d, eng, scan=False):
+    """The FULL-width hand-off arrays d['Fft.Cur'|'Fft.Max'|'Fft.Min'|'Fft.Avg'] and the whole [128, W] waterfall
+    buffer, read from the device: on demand (RAW / CONV Levels plots, K:205-221), and once when a run ends
+    (SaveSigLvls K:736-748, callers of main())."""
+    st = eng.scan_state() if scan else eng.state()
+    for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg"):
+        d[k] = st[k]
+    if not scan:
+        for flag, k in (("bDataMax", "Fft.Max"), ("bDataMin", "Fft.Min"), ("bDataAvg", "Fft.Avg")):
+            if not d[flag]:
+                d[k] = None                                                 # still None in the reference, K:471-476
+    d["fftHM"], d["fftHMIndex"] = st["fftHM"], st["hm_index"]
+    d["handoff.bytes"] = sum(st[k].size for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg", "fftHM")) * 4
+    return st
+
+
+def _handoff(d, eng, freqs, scan=False):
+    """What one frame (zeroSpan, K:477-504) or one pass (scan, K:669-697 + K:729) hands to the plots.  With a
+    decimating pltCompress everything is reduced on the device and ONE call (ksa_read_view) brings back the four
+    xRes-point curves, the peak markers of the last plotted curve and the one new waterfall row: 4*xRes + xRes
+    floats instead of 4*N + 128*W.  RAW / CONV plots need the full curves and materialise them."""
+    if not _view_on_device(d, len(freqs)):
+        _materialize(d, eng, scan)
+        _plot_heatmap(d, d["fftHM"])
+        _plot_levels(d, freqs, d["Fft.Cur"])
+        return
+    last = None
+    for flag in ("bDataMax", "bDataMin", "bDataAvg", "bDataCur"):        # plotting order of K:489-503: the last one is marked
+        if d[flag]:
+            last = flag[5:].lower()
+    if d.get("Levels.key") != (id(freqs), d["xRes"]):
+        d["Levels.x"], d["Levels.key"] = _plotcompress(d, freqs, "AVG"), (id(freqs), d["xRes"])
+    xs = d["Levels.x"]
+    count = d["pltHighsNumMarkers"]
+    cell = (xs[-1] - xs[0]) / (len(xs) - 1) if len(xs) > 1 else 1.0
+    delta = d["pltHighsDelta4Marking"] * (xs[-1] - xs[0])
+    want_marks = last is not None and 1 <= count <= 64 and len(xs) > 1
+    lv, idx, lvl, rows, hm_index = eng.view(d["xRes"], d["pltCompress"], curve=last if want_marks else None,
+                                            min_sep=delta / cell, count=count, hm_rows=1, scan=scan)
+    d["handoff.bytes"] = (lv.size + rows.size + 2 * len(idx)) * 4
+    d["Levels"] = {"x": xs, "max": lv[1], "min": lv[2], "avg": lv[3], "cur": lv[0]}
+    d["fftHM"][(hm_index - 1) % _engine.HM_ROWS] = rows[0]               # the host copy of the ring takes the new row (K:480 / K:697)
+    d["fftHMIndex"] = hm_index
+    _plot_heatmap(d, d["fftHM"])
+    drawing = d.get("plt") is not None and d["bPltLevels"]
+    if drawing:
+        d["AxLevels"].cla()
+        if d["bGrid"]:
+            d["AxLevels"].grid(True)
+        for flag, row, colour in (("bDataMax", 1, "r"), ("bDataMin", 2, "y"), ("bDataAvg", 3, "g"), ("bDataCur", 0, "b")):
+            if d[flag]:
+                d["AxLevels"].plot(xs, lv[row], colour)
+    if last is not None:
+        marked = [(float(xs[i]), float(v)) for i, v in zip(idx, lvl)] if want_marks else []
+        _show_highs(d, marked)
+
+
+def _show_highs(d, marked):
+    """The drawing half of plot_highs (K:263-267)."""
     d["Highs"] = marked
     if d.get("plt") is not None and d["bPltLevels"]:
         d["AxFreqs"].clear()
@@ -431,33 +504,11 @@ def plot_highs(d, freqs, levels, eng=None, curve=None, scan=False):
         for n, (f, lvl) in enumerate(marked):
             d["AxLevels"].plot(f, lvl, "o", label=f)
             d["AxFreqs"].text(0.1, 1.0 - 0.1 * (n + 1), "{}:{}".format(round(f / 1e6, 8), round(lvl, 2)))
-    return marked
 
 
-def _plot_levels(d, freqs, cur, eng=None, scan=False):
-    """Levels hand-off (K:485-504 / K:670-688).  With pltCompress AVG|MAX|MIN the four curves are decimated to
-    xRes points on the device (ksa_read_levels) and only those cross PCIe; RAW / CONV use the full arrays."""
+def _plot_levels(d, freqs, cur):
+    """Levels hand-off from FULL host arrays (K:485-504 / K:670-688): the RAW / CONV modes, which plot every bin."""
     fmax, fmin, favg, fcur = _adj_siglvls(d, cur)
-    mode = d["pltCompress"]
-    if eng is not None and mode in ("AVG", "MAX", "MIN") and len(freqs) // d["xRes"] > 0 and len(freqs) % d["xRes"] == 0:
-        lv = eng.levels(d["xRes"], mode, scan=scan)               # rows: cur, max, min, avg (baseline-adjusted)
-        xs = _plotcompress(d, freqs, "AVG")
-        curves = (("bDataMax", lv[1], "r"), ("bDataMin", lv[2], "y"), ("bDataAvg", lv[3], "g"), ("bDataCur", lv[0], "b"))
-        x = y = None
-        if d.get("plt") is not None and d["bPltLevels"]:
-            d["AxLevels"].cla()
-            if d["bGrid"]:
-                d["AxLevels"].grid(True)
-        last = None
-        for flag, data, colour in curves:
-            if d[flag]:
-                x, y, last = xs, data, flag[5:].lower()                     # bDataMax -> "max"
-                if d.get("plt") is not None and d["bPltLevels"]:
-                    d["AxLevels"].plot(x, y, colour)
-        d["Levels"] = {"x": xs, "max": lv[1], "min": lv[2], "avg": lv[3], "cur": lv[0]}
-        if x is not None:
-            plot_highs(d, x, y, eng, last, scan)                          # markers of the last plotted curve (K:504)
-        return
     x = y = None
     curves = (("bDataMax", fmax, "r"), ("bDataMin", fmin, "y"), ("bDataAvg", favg, "g"), ("bDataCur", fcur, "b"))
     if d.get("plt") is not None and d["bPltLevels"]:
@@ -500,6 +551,7 @@ def zero_span(d):
     print("ZeroSpan: min[{}] max[{}]".format(min(freqs), max(freqs)))
     eng = get_engine(d)
     eng.reset()
+    d["fftHM"], d["fftHMIndex"] = np.zeros((_engine.HM_ROWS, eng.hm_width)), 0     # K:456; the device ring starts the same
     prev = time.time()
     for i in range(d["prgLoopCnt"]):
         now = time.time()
@@ -521,18 +573,10 @@ def zero_span(d):
                 eng.frame_spectrum(cur)
         if d["cmd.stop"]:
             break
-        st = eng.state()
-        for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg"):
-            d[k] = st[k]
-        if not d["bDataMax"]:
-            d["Fft.Max"] = None
-        if not d["bDataMin"]:
-            d["Fft.Min"] = None
-        if not d["bDataAvg"]:
-            d["Fft.Avg"] = None
-        d["fftHM"], d["fftHMIndex"] = st["fftHM"], st["hm_index"]
-        _plot_heatmap(d, d["fftHM"])
-        _plot_levels(d, freqs, d["Fft.Cur"], eng)
+        _handoff(d, eng, freqs)                  # xRes-sized curves + markers + the new waterfall row (row f2)
+    if _materialize(d, eng)["frames"] == 0:      # full-width arrays once, for SaveSigLvls and whoever called main()
+        for k in ("Fft.Max", "Fft.Min", "Fft.Avg", "Fft.Cur"):
+            d[k] = None                          # no frame ran: the curves are still None (K:427-430)
 
 
 def zero_span_save(d):
@@ -614,6 +658,7 @@ def scan_range(d):
     # one pass of capture blocks in page-locked host memory; the library stages it to the GPU (ksa_scan_pass_c64 / _u8)
     stage = _engine.PinnedBuffer((steps, d["fullSize"] * 2) if u8 else (steps, d["fullSize"]), np.uint8 if u8 else np.complex64)
     blocks = stage.array
+    d["fftHM"], d["fftHMIndex"] = eng.hm_rows(0, _engine.HM_ROWS, scan=True), 0    # K:613-614, read once
     prev = time.time()
     for i in range(d["prgLoopCnt"]):
         if d["cmd.stop"]:
@@ -631,12 +676,8 @@ def scan_range(d):
             blocks[s] = sdr_read(d["sdr"], d["fullSize"], raw=u8)
         eng.set_flags(d["bDataMax"], d["bDataMin"], True)
         eng.scan_pass(blocks, step_ok=ok)
-        st = eng.scan_state()
-        for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg"):
-            d[k] = st[k]
-        d["fftHM"], d["fftHMIndex"] = st["fftHM"], st["hm_index"]
-        _plot_levels(d, d["freqsAll"], d["Fft.Cur"], eng, scan=True)
-        _plot_heatmap(d, d["fftHM"])
+        _handoff(d, eng, d["freqsAll"], scan=True)
+    _materialize(d, eng, scan=True)
     stage.close()
 
 

@@ -375,7 +375,7 @@ def test_bench_secondary_configs_one_gpu(cfg, extra):
     d = _bench(["--config", str(cfg), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.3"] + extra)
     assert d["config"]["baseline_config"] == cfg and d["n_gpus"] == 1 and d["unit"] == "FFT/s"
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and 0 < rf["flop_frac"] < 1 and rf["frac_step"] <= rf["frac"] * 1.001
+    assert rf["bound"] == {3: "valu", 4: "valu", 5: "hbm (Z round trip)"}[cfg] and rf["limiter"] and 0 < rf["frac"] < 1 and 0 < rf["flop_frac"] < 1 and rf["frac_step"] <= rf["frac"] * 1.001
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
 
 

@@ -174,7 +174,10 @@ def test_pair_kernel_matches_single_frame_kernel(ksa, torch_cuda, q, fmt, mode):
     instead of 15 table entries); a few frames are checked against the oracle as well."""
     torch = torch_cuda
     n, full = 1024, 8192
-    frames = 2 * 256 * 2 + 513                       # above the switch-over, odd
+    probe = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="kaiser", cumu_mode=mode, xres=256, max_frames=1)
+    switch_over = 2 * probe.kernel_info()["grid"]    # ksa_api.hip: batches of >= 2 x CUs x workgroups-per-CU frames take the pair kernel
+    probe.close()
+    frames = switch_over + 513                       # above the switch-over, odd
     distinct = 37
     x = orc.synth_iq(full * distinct, 4321 + n).astype(np.complex64).reshape(distinct, full)
     idx = np.arange(frames) % distinct
@@ -185,6 +188,7 @@ def test_pair_kernel_matches_single_frame_kernel(ksa, torch_cuda, q, fmt, mode):
         dev = torch.view_as_real(torch.from_numpy(x[idx])).cuda()
         code = ksa.FMT_C64
     outs = []
+    assert 500 < switch_over
     for chunk in (frames, 500):
         eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="kaiser", cumu_mode=mode, xres=256, max_frames=frames)
         assert eng.kernel_info()["path"] == 4

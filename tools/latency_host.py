@@ -47,3 +47,26 @@ for name, n, q, start, end, win in (("fmScan", 16384, 0.1, 88e6, 108e6, "kaiser"
               (name, label, dt * 1e6, steps, full, steps * full / dt / 1e6, arg.nbytes / dt / 1e9))
     pinned.close()
     eng.close()
+
+# per-frame plot hand-off: the full state + Levels + markers (rounds 1-3) vs ksa_read_view (round 4)
+for n, xres in ((4096, 512), (16384, 512), (65536, 512)):
+    full = orc.full_size(n, 2.4e6 if n < 65536 else 1e9)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", xres=xres)
+    eng.frame(orc.synth_iq(full, 3).astype(np.complex64))
+    def old():
+        st = eng.state()
+        lv = eng.levels(xres, "AVG")
+        idx, lvl = eng.highs(xres, "AVG", "cur", min_sep=0.025 * xres, count=5)
+        return sum(st[k].size for k in ("Fft.Cur", "Fft.Max", "Fft.Min", "Fft.Avg", "fftHM")) * 4 + lv.size * 4 + 2 * len(idx) * 4
+    def new():
+        lv, idx, lvl, rows, hm_index = eng.view(xres, "AVG", curve="cur", min_sep=0.025 * xres, count=5, hm_rows=1)
+        return (lv.size + rows.size + 2 * len(idx)) * 4
+    for name, fn in (("state + levels + highs", old), ("ksa_read_view", new)):
+        for _ in range(5):
+            nbytes = fn()
+        t0 = time.perf_counter(); reps = 200
+        for _ in range(reps):
+            fn()
+        dt = (time.perf_counter() - t0) / reps
+        print("hand-off N=%-6d xRes=%d %-24s %8.1f us/frame  %8d bytes over PCIe" % (n, xres, name, dt * 1e6, nbytes))
+    eng.close()

@@ -57,8 +57,32 @@ if dom and bench:
         except Exception:
             pass
     key = "%d:%s:%d" % (cfg["baseline_config"], fmt, units)
-    rec["entries"][key] = {"hbm_bytes_per_launch": per_step, "csrc_sha256": B.csrc_sha256(), "source": "profiles/%s_pmc.json" % tag,
-                           "kernels": sorted(dom)}
+    ent = {"hbm_bytes_per_launch": per_step, "csrc_sha256": B.csrc_sha256(), "source": "profiles/%s_pmc.json" % tag,
+           "kernels": sorted(dom)}
+    # what the stage keeps busy (MI355X_MICROARCH.md, LDS / counters): LDS-array cycles and VALU issue slots over the
+    # stage's shader cycles (GRBM_GUI_ACTIVE counts every XCD: / 8), on all 256 CUs x 4 SIMDs (2 clk per wave64 fp32 issue)
+    NUM_CU = 256
+    sq = [c for c in dom.values() if "GRBM_GUI_ACTIVE" in c and "SQ_LDS_IDX_ACTIVE" in c and "SQ_INSTS_VALU" in c]
+    if sq:
+        cyc = sum(c["GRBM_GUI_ACTIVE"] / 8.0 * c["launches_pmc_sq"] for c in sq)
+        lds = sum(c["SQ_LDS_IDX_ACTIVE"] * c["launches_pmc_sq2"] for c in sq)
+        ent["lds_frac"] = lds / (NUM_CU * cyc)
+        ent["lds_conflict_ratio"] = (sum(c["SQ_LDS_BANK_CONFLICT"] * c["launches_pmc_sq2"] for c in sq) / lds) if lds else 0.0
+        ent["valu_issue_frac"] = sum(c["SQ_INSTS_VALU"] * c["launches_pmc_sq"] for c in sq) * 2.0 / (NUM_CU * 4 * cyc)
+        ent["lds_insts_per_step"] = sum(c["SQ_INSTS_LDS"] * c["launches_pmc_sq"] for c in sq) / steps_in_pmc_run
+        ent["lds_wait_ratio"] = (sum(c.get("SQ_WAIT_INST_LDS", 0.0) * c["launches_pmc_sq2"] for c in sq) /
+                                 max(1.0, sum(c.get("SQ_WAVE_CYCLES", 0.0) * c["launches_pmc_sq"] for c in sq)))
+        # shader clock held during the stage: cycles / time of the same kernels in the --stats pass
+        try:
+            ns = {}
+            for r in csv.DictReader(open(os.path.join(dst, tag + "_kernel_stats.csv"))):
+                ns[r["Name"].split("(")[0][:70]] = float(r["AverageNs"])
+            t = sum(ns[k] * c["launches_pmc_sq"] for k, c in dom.items() if k in ns and c in sq)
+            if t > 0:
+                ent["shader_clock_ghz"] = cyc / t
+        except Exception:
+            pass
+    rec["entries"][key] = ent
     json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
     alg = bench["roofline"]["algorithmic_bytes_per_launch"]
     print("%s: traffic %.3f GB per step vs algorithmic %.3f GB (x%.2f)" % (key, per_step / 1e9, alg / 1e9, per_step / alg))
