@@ -28,10 +28,16 @@ def torch_cuda():
     return torch
 
 
+def dev_of(torch, r):
+    """Engine r of a multi-engine test lives on GPU r % device_count: on a node every engine gets its own device (peer
+    copies, cross-device events), on the one-GPU box they share device 0."""
+    return r % torch.cuda.device_count()
+
+
 # ------------------------------------------------------------------------------- SURVEY 8(b) allreduce_state
 @pytest.mark.parametrize("world,fpr,idx0,n", [(2, 100, 77, 1024), (3, 40, 0, 4096), (8, 16, 120, 1024), (8, 200, 5, 256)])
 def test_allreduce_state_engines_of_one_process(ksa, torch_cuda, world, fpr, idx0, n):
-    """ksa_allreduce_state: `world` engines (here all on GPU 0; one per GPU on a node) each hold an uncommitted time
+    """ksa_allreduce_state: `world` engines (engine r on GPU r % device_count: one per GPU on a node) each hold an uncommitted time
     chunk; afterwards every engine holds the state of a single engine that ran the whole run (K:470-484) -- the same
     bits on every handle.  Two steps: stale ring rows, the has-previous Avg path and the ring wrap are covered."""
     torch = torch_cuda
@@ -39,16 +45,19 @@ def test_allreduce_state_engines_of_one_process(ksa, torch_cuda, world, fpr, idx
     total = world * fpr
     x = orc.synth_iq(full * total * 2, 131 + world).astype(np.complex64).reshape(2, total, full)
     dev = torch.view_as_real(torch.from_numpy(x)).cuda()
-    mk = lambda mf: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=xres, max_frames=mf)
+    mk = lambda mf, d=0: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=xres, max_frames=mf, device=d)
     one = mk(total)
     one.set_hm_index(idx0)
-    ranks = [mk(fpr) for _ in range(world)]
+    ranks = [mk(fpr, dev_of(torch, r)) for r in range(world)]
+    chunks = [[dev[step, r * fpr:(r + 1) * fpr].to("cuda:%d" % dev_of(torch, r)) for r in range(world)] for step in range(2)]
+    for d in range(torch.cuda.device_count()):
+        torch.cuda.synchronize(d)
     hm_index = idx0
     for step in range(2):
         one.frames_dev(dev[step], ksa.FMT_C64, total)
         for r, eng in enumerate(ranks):
             eng.set_hm_index((hm_index + r * fpr) % 128)
-            eng.frames_dev(dev[step, r * fpr:(r + 1) * fpr], ksa.FMT_C64, fpr, first_index=r * fpr, total_frames=total, commit=False)
+            eng.frames_dev(chunks[step][r], ksa.FMT_C64, fpr, first_index=r * fpr, total_frames=total, commit=False)
         ksa.allreduce_state(ranks, fpr, hm_index)
         hm_index = (hm_index + total) % 128
         want = one.state()
@@ -173,12 +182,15 @@ def test_one_band_scan_with_adj_siglvls(ksa, torch_cuda):
 
 # ------------------------------------------------------------------------------- band-sharded scan
 def _own_spectra(ksa, torch, eng, x_dev, passes, steps, lo, hi):
-    """[passes][hi-lo][N] clipped dB spectra of the bands [lo, hi) of every pass (pass-major device block)."""
+    """[passes][hi-lo][N] clipped dB spectra of the bands [lo, hi) of every pass (pass-major device block on the engine's GPU)."""
     mine = hi - lo
-    own = torch.empty((passes, max(mine, 1), eng.fft_size), dtype=torch.float32, device="cuda")
+    where = "cuda:%d" % eng.device
+    own = torch.empty((passes, max(mine, 1), eng.fft_size), dtype=torch.float32, device=where)
     if mine:
-        iq = x_dev[:, lo:hi].contiguous()
-        eng.curscan_dev(iq, ksa.FMT_C64, passes * mine, own, out_mode=ksa.OUT_DB_CLIP)
+        iq = x_dev[:, lo:hi].contiguous().to(where)
+        torch.cuda.synchronize(eng.device)
+        eng.scan_spectra_dev(iq, ksa.FMT_C64, passes * mine, own)
+        eng.synchronize()           # (iq is a temporary of this function)
     return own
 
 
@@ -198,10 +210,10 @@ def test_band_sharded_scan_equals_one_engine(ksa, torch_cuda, n, q, world, passe
     xres = 64
     win = orc.window_table("hanning", n)
     ref = orc.ScanState(n, start, end, fs, GAIN, 1e-7, xres, scan_non_overlap=q, base_is_raw=base_raw)
-    mk = lambda mf: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=1e-7, xres=xres,
-                                       max_frames=mf, scan_total_entries=ref.total, scan_non_overlap=q)
+    mk = lambda mf, d=0: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=1e-7, xres=xres,
+                                            max_frames=mf, scan_total_entries=ref.total, scan_non_overlap=q, device=d)
     one = mk(steps * passes)
-    ranks = [mk(max(1, passes * (-(-steps // world)))) for _ in range(world)]
+    ranks = [mk(max(1, passes * (-(-steps // world))), dev_of(torch, r)) for r in range(world)]
     for e in ranks + [one]:
         e.scan_set_base_is_raw(base_raw)
     for batch in range(2):
@@ -241,7 +253,7 @@ def test_band_sharded_fmscan_golden_eight_ranks(ksa, torch_cuda):
     x = _regen_iq(g, full * steps * passes).reshape(passes, steps, full)
     x_dev = torch.view_as_real(torch.from_numpy(x)).cuda()
     world = 8
-    ranks = [_scan_engine(ksa, g, 3 * passes) for _ in range(world)]
+    ranks = [_scan_engine(ksa, g, 3 * passes, device=dev_of(torch, r)) for r in range(world)]
     own = []
     for r, eng in enumerate(ranks):
         lo, hi, *_ = eng.scan_shard(steps, r, world)
@@ -504,7 +516,7 @@ def test_plain_c_client(tmp_path):
 
 
 # ------------------------------------------------------------------------------- the torch.distributed scan driver on real engines
-def _sharded_scan_rank(rank, world, port, n, sq, passes, out_path):
+def _sharded_scan_rank(rank, world, port, n, sq, passes, out_path, backend="gloo"):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -514,14 +526,20 @@ def _sharded_scan_rank(rank, world, port, n, sq, passes, out_path):
     import ksa_oracle as orc_
     ksa = importlib.import_module("prgs-sdr-kspecanal_amd")
     dmod = importlib.import_module("prgs-sdr-kspecanal_amd.distributed")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    if backend == "nccl":            # a node: one GPU per rank, RCCL
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:                            # the one-GPU box: every rank on device 0, gloo
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+    mydev = torch.cuda.current_device()
     full, fs, start = 8 * n, 2.4e6, 100e6
     end = start + 5 * fs
     steps = len(orc_.scan_steps(start, end, fs, sq))
     total = 5 * n
     eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=1e-7, xres=64,
-                             max_frames=max(1, passes * (-(-steps // world))), scan_total_entries=total, scan_non_overlap=sq)
+                             max_frames=max(1, passes * (-(-steps // world))), scan_total_entries=total, scan_non_overlap=sq, device=mydev,
+                             stream=torch.cuda.current_stream().cuda_stream)
     run = dmod.ShardedScan(eng, rank, world)
     lo, hi = dmod.step_range(steps, rank, world)
     for batch in range(2):
@@ -574,6 +592,41 @@ def test_sharded_scan_driver_three_ranks_on_one_gpu(ksa, torch_cuda, tmp_path, n
         for k in CURVES + ("fftHM",):
             assert np.array_equal(got[k], want[k]), "%s on rank %d" % (k, r)
     assert majors == [1 if -(-steps // world) <= 8 else 0] * world          # which path every rank took
+
+
+@pytest.mark.parametrize("n,sq,passes", [(256, 0.5, 3), (64, 0.125, 2), (256, 0.5, 130)])
+def test_sharded_scan_driver_nccl_one_gpu_per_rank(ksa, torch_cuda, tmp_path, n, sq, passes):
+    """The same driver test on a node: world = device_count ranks, one GPU each, RCCL (batch_isend_irecv halos, the row
+    all-gather).  Every rank's gathered state equals ONE engine's, bit for bit.  Skipped on the one-GPU box."""
+    import socket
+    import torch.multiprocessing as mp
+    torch = torch_cuda
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL with N > 1 ranks)")
+    full, fs, start = 8 * n, 2.4e6, 100e6
+    end = start + 5 * fs
+    steps = len(orc.scan_steps(start, end, fs, sq))
+    one = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=1e-7, xres=64,
+                             max_frames=steps * passes, scan_total_entries=5 * n, scan_non_overlap=sq)
+    for batch in range(2):
+        x = orc.synth_iq(full * steps * passes, 300 + batch).astype(np.complex64).reshape(passes, steps, full)
+        ok = np.ones((passes, steps), dtype=np.uint8)
+        ok[0, steps // 2] = 0
+        one.scan_passes_dev(torch.view_as_real(torch.from_numpy(x)).cuda(), ksa.FMT_C64, steps, passes, step_ok=ok.reshape(-1))
+    want = one.scan_state()
+    one.close()
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_sharded_scan_rank, args=(world, port, n, sq, passes, out, "nccl"), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(out % r)
+        assert int(got["hm_index"]) == want["hm_index"]
+        for k in CURVES + ("fftHM",):
+            assert np.array_equal(got[k], want[k]), "%s on rank %d" % (k, r)
 
 
 # ------------------------------------------------------------------------------- row A0: the unpack convention is a parameter

@@ -239,3 +239,242 @@ def test_library_reads_no_environment_switch(ksa, torch_cuda):
     nm = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "prgs-sdr-kspecanal_amd", "libksa.so")],
                         capture_output=True, text=True)
     assert nm.returncode == 0 and "getenv" not in nm.stdout
+
+
+# ------------------------------------------------------------------------------- BASELINE configs[3]: quickFullScan, band shard across 8
+def test_band_sharded_quickfullscan_golden_eight_ranks(ksa, torch_cuda):
+    """the configuration BASELINE configs[3] literally names -- the 1 226-band quickFullScan pass of the
+    reference-run golden through ksa_scan_allstitch with 8 engines (153-154 bands each: the pass-major share, 32-column
+    halos from the left neighbour), engine r on GPU r % device_count.  Curves against the golden's sampled bins and
+    checksums, waterfall rows against its rows, ring identical on every engine (K:622-668, K:696-697)."""
+    from test_gpu_round3 import _own_spectra, dev_of
+    torch = torch_cuda
+    g = golden("scan_quickfull_n64")
+    n, full, passes, steps = int(g["fft_size"]), int(g["full"]), int(g["passes"]), int(g["steps"])
+    assert n == 64 and steps == 1226
+    x = _regen_iq(g, full * steps * passes).reshape(passes, steps, full)
+    x_dev = torch.view_as_real(torch.from_numpy(x)).cuda()
+    world = 8
+    ranks = [_scan_engine(ksa, g, 154 * passes, device=dev_of(torch, r)) for r in range(world)]
+    own, shares = [], []
+    for r, eng in enumerate(ranks):
+        lo, hi, nhalo, e_lo, e_hi = eng.scan_shard(steps, r, world)
+        shares.append(hi - lo)
+        assert nhalo == (1 if r else 0)
+        own.append(_own_spectra(ksa, torch, eng, x_dev, passes, steps, lo, hi))
+    assert sorted(set(shares)) == [153, 154] and sum(shares) == steps
+    ksa.scan_allstitch(ranks, own, steps, passes)
+    st = ksa.scan_gather_state(ranks, steps)
+    rings = [e.scan_state() for e in ranks]
+    st.update(fftHM=rings[0]["fftHM"])
+    assert all(rg["hm_index"] == int(g["hm_index"]) and rg["passes"] == passes for rg in rings)
+    assert all(np.array_equal(rg["fftHM"], rings[0]["fftHM"]) for rg in rings)
+    _check_sampled(st, g, "quickFullScan 8 ranks")
+    assert_db(rings[0]["fftHM"][:passes], g["hm_rows"][:passes], what="quickFullScan 8 ranks waterfall rows")
+    # and bit for bit what ONE engine gives for the same passes
+    one = _scan_engine(ksa, g, steps * passes)
+    one.scan_passes_dev(x_dev, ksa.FMT_C64, steps, passes)
+    want = one.scan_state()
+    for k in CURVES:
+        assert np.array_equal(st[k], want[k]), k
+    assert np.array_equal(rings[0]["fftHM"], want["fftHM"])
+    for e in ranks + [one]:
+        e.close()
+
+
+def test_scan_allstitch_refuses_before_touching_any_engine(ksa, torch_cuda):
+    """every pointer is validated before the first launch -- a null own_db for a rank that owns bands must
+    leave the pass counters and the state of ALL engines as they were, and the caller's current device is handed back."""
+    torch = torch_cuda
+    n, full = 256, 2048
+    mk = lambda: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=1e-7, xres=64,
+                                    max_frames=16, scan_total_entries=2 * n)
+    a, b = mk(), mk()
+    steps, passes = 4, 2
+    own = torch.zeros((passes, 2, n), dtype=torch.float32, device="cuda")
+    before = [e.scan_state() for e in (a, b)]
+    cur = torch.cuda.current_device()
+    with pytest.raises(ksa.KsaError, match="own_db_dev"):
+        ksa.scan_allstitch([a, b], [own, None], steps, passes)
+    after = [e.scan_state() for e in (a, b)]
+    for x, y in zip(before, after):
+        assert x["passes"] == y["passes"] == 0 and all(np.array_equal(x[k], y[k]) for k in CURVES + ("fftHM",))
+    assert torch.cuda.current_device() == cur
+    ksa.scan_allstitch([a, b], [own, own], steps, passes)        # and the engines are still usable
+    assert a.scan_state()["passes"] == passes
+    for e in (a, b):
+        e.close()
+
+
+# ------------------------------------------------------------------------------- SURVEY 8 row f2: the per-frame hand-off
+def test_read_view_equals_full_state(ksa, torch_cuda):
+    """ksa_read_view (levels + markers + newest ring rows in one call) against the separate full-width reads, zeroSpan and
+    scan; ksa_read_hm_rows across the ring's wrap."""
+    n, full, xres = 4096, 32768, 512
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=xres, max_frames=1)
+    x = orc.synth_iq(full * 131, 12).astype(np.complex64).reshape(131, full)
+    for f in range(131):
+        eng.frame(x[f])
+    st = eng.state()
+    lv, idx, lvl, rows, hm_index = eng.view(xres, "AVG", curve="max", min_sep=0.025 * xres, count=5, hm_rows=3)
+    assert hm_index == st["hm_index"] == 131 % 128
+    assert np.array_equal(lv, eng.levels(xres, "AVG"))
+    i2, l2 = eng.highs(xres, "AVG", "max", min_sep=0.025 * xres, count=5)
+    assert np.array_equal(idx, i2) and np.array_equal(lvl, l2) and len(idx) == 5
+    assert np.array_equal(rows, st["fftHM"][[0, 1, 2]])                       # frames 128, 129, 130 -> ring rows 0, 1, 2
+    assert np.array_equal(eng.hm_rows(126, 4), st["fftHM"][[126, 127, 0, 1]])  # wraps
+    lv0, idx0, lvl0, rows0, _ = eng.view(xres, "MAX", hm_rows=0)             # no markers, no rows
+    assert len(idx0) == 0 and rows0.shape[0] == 0 and np.array_equal(lv0, eng.levels(xres, "MAX"))
+    with pytest.raises(ksa.KsaError):
+        eng.view(xres, "AVG", scan=True)
+    eng.close()
+
+
+def test_zero_span_handoff_moves_xres_sized_data(ksa, torch_cuda):
+    """kspecanal.zero_span's per-frame hand-off (K:477-504): with a decimating pltCompress only the four xRes-point
+    curves, the markers and ONE waterfall row cross PCIe per frame (d['handoff.bytes']); the host copy of the ring
+    assembled row by row, d['Levels'] and d['Highs'] equal what the full state gives; RAW plots still get full arrays."""
+    import importlib
+    K = importlib.import_module("prgs-sdr-kspecanal_amd.kspecanal")
+    seen = []
+    orig = K._handoff
+
+    def spy(d, eng, freqs, scan=False):
+        orig(d, eng, freqs, scan)
+        st = eng.scan_state() if scan else eng.state()
+        seen.append((d["handoff.bytes"], np.array_equal(d["fftHM"], st["fftHM"]), d["fftHMIndex"] == st["hm_index"],
+                     dict(d.get("Levels", {})), list(d.get("Highs", [])), eng.levels(d["xRes"], d["pltCompress"], scan=scan) if K._view_on_device(d, len(freqs)) else None))
+    K._handoff = spy
+    try:
+        d = K.main(["zeroSpan", "fftSize", "4096", "window", "hanning", "prgLoopCnt", "5", "centerFreq", "100.3e6", "xRes", "256",
+                    "pltCompress", "MAX", "bPltLevels", "false", "bPltHeatMap", "false", "source", "synth"])
+        assert len(seen) == 5
+        for nbytes, ring_ok, idx_ok, levels, highs, lv in seen:
+            assert nbytes <= (4 * 256 + 256 + 2 * 5) * 4 and ring_ok and idx_ok
+            assert np.array_equal(levels["cur"], lv[0]) and np.array_equal(levels["max"], lv[1]) and len(highs) == 5
+        full_bytes = (4 * 4096 + 128 * 256) * 4
+        assert seen[-1][0] * 20 < full_bytes
+        assert d["Fft.Cur"].shape == (4096,) and d["fftHM"].shape == (128, 256)      # materialised once at the end
+        seen.clear()
+        d = K.main(["zeroSpan", "fftSize", "4096", "prgLoopCnt", "2", "xRes", "256", "pltCompress", "RAW", "bPltLevels", "false",
+                    "bPltHeatMap", "false", "source", "synth"])
+        assert [s[0] for s in seen] == [full_bytes] * 2 and all(s[1] and s[2] for s in seen)
+        seen.clear()
+        d = K.main(["scan", "startFreq", "100e6", "endFreq", "104.8e6", "fftSize", "1024", "window", "hanning", "prgLoopCnt", "3",
+                    "xRes", "128", "bPltLevels", "false", "bPltHeatMap", "false", "source", "synth"])
+        assert len(seen) == 3 and all(s[1] and s[2] for s in seen)
+        assert all(s[0] <= (4 * 128 + 128 + 2 * 5) * 4 for s in seen)
+        assert d["Fft.Avg"].shape == (2 * 1024,)
+    finally:
+        K._handoff = orig
+
+
+# ------------------------------------------------------------------------------- first contact with a multi-GPU node (VERDICT r03 item 1)
+def _node_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("cfg,extra", [(2, ["--frames", "1024"]), (3, ["--passes", "4"]), (4, ["--passes", "8"]), (5, ["--frames", "16"])])
+def test_bench_lines_prove_their_topology_gloo_rehearsal(cfg, extra):
+    """`bench.py --gpus 3` over gloo on this GPU: the N > 1 line carries the `ranks` block gathered from the ranks
+    themselves, the cross-rank state digest, and (zeroSpan) the strong sub-record -- what a node run will print, here with
+    three ranks sharing one device (and saying so)."""
+    d = _bench(["--gpus", "3", "--config", str(cfg), "--steps", "2", "--warmup", "1", "--no-cpu"] + extra, env={"KSA_BENCH_BACKEND": "gloo"})
+    rk = d["ranks"]
+    assert rk["backend"] == "gloo" and rk["world_size"] == 3 and len(rk["per_rank"]) == 3 and rk["rccl_version"] is None
+    assert sorted(r["rank"] for r in rk["per_rank"]) == [0, 1, 2] and len({r["pid"] for r in rk["per_rank"]}) == 3
+    assert all("name" in r and "host" in r and "device" in r for r in rk["per_rank"])
+    assert rk["distinct_devices"] == min(3, _node_devices()) and ("REHEARSAL" in d["multi_gpu_note"]) == (rk["distinct_devices"] < 3)
+    assert d["state_identical_across_ranks"] is True and d["ranks_differing_from_rank0"] == [] and len(d["state_sha256_rank0"]) == 64
+    if cfg in (2, 5):
+        s = d["strong"]
+        assert d["scaling"] == "weak" and s["scaling"] == "strong" and s["frames_per_gpu_per_step"] * 3 <= d["config"]["frames_per_gpu_per_step"]
+        assert s["value"] > 0 and s["ms_per_step"] > 0
+    else:
+        assert d["scaling"] == "strong" and "strong" not in d
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "valu", "hbm (Z round trip)") and rf["limiter"]
+
+
+@pytest.mark.parametrize("cfg,extra", [(2, ["--frames", "1024"]), (5, ["--frames", "16"]), (3, ["--passes", "4"]), (4, ["--passes", "8"])])
+def test_bench_inprocess_leg(cfg, extra):
+    """`bench.py --inprocess --gpus 4`: one process, four engines (engine r on GPU r % device_count) merged by
+    ksa_allreduce_state / ksa_scan_allstitch -- the torch-free multi-GPU form has a bench leg of its own."""
+    d = _bench(["--inprocess", "--gpus", "4", "--config", str(cfg), "--steps", "2", "--warmup", "1", "--no-cpu"] + extra)
+    assert d["n_gpus"] == 4 and d["value"] > 0 and "inprocess" in d["config"]["driver"]
+    assert d["ranks"]["world_size"] == 4 and d["ranks"]["distinct_devices"] == min(4, _node_devices())
+    assert d["state_identical_across_ranks"] is True
+
+
+def test_bench_nccl_over_every_visible_device():
+    """On a node: `bench.py --gpus device_count` over RCCL, one rank per GPU.  The record must show device_count distinct
+    devices and bit-identical state on every rank.  Skipped on the one-GPU box."""
+    nd = _node_devices()
+    if nd < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL with N > 1 ranks)")
+    for cfg, extra in ((2, ["--frames", "4096"]), (3, ["--passes", "16"]), (4, ["--passes", "32"]), (5, ["--frames", "64"])):
+        d = _bench(["--gpus", str(nd), "--config", str(cfg), "--steps", "3", "--warmup", "1", "--no-cpu"] + extra)
+        rk = d["ranks"]
+        assert rk["backend"] == "nccl" and rk["world_size"] == nd and rk["distinct_devices"] == nd and rk["rccl_version"]
+        assert d["state_identical_across_ranks"] is True and "REHEARSAL" not in d["multi_gpu_note"]
+
+
+def _zerospan_nccl_rank(rank, world, port, out_path):
+    import importlib
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p_ in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    import ksa_oracle as orc_
+    ksa = importlib.import_module("prgs-sdr-kspecanal_amd")
+    dmod = importlib.import_module("prgs-sdr-kspecanal_amd.distributed")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    n, full, fpr = 1024, 8192, 150
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=128, max_frames=fpr, device=rank,
+                             stream=torch.cuda.current_stream().cuda_stream)
+    run = dmod.ShardedZeroSpan(eng, rank, world)
+    for step in range(2):
+        x = orc_.synth_iq(full * fpr * world, 900 + step).astype(np.complex64).reshape(world, fpr, full)
+        run.step(torch.view_as_real(torch.from_numpy(x[rank])).cuda(), ksa.FMT_C64, fpr)
+    torch.cuda.synchronize()
+    st = eng.state()
+    np.savez(out_path % rank, hm_index=st["hm_index"], frames=st["frames"], **{k: st[k] for k in CURVES + ("fftHM",)})
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+def test_rccl_merge_path_world_device_count(ksa, torch_cuda, tmp_path):
+    """test_rccl_merge_path_single_rank's sibling for a node: world = device_count ranks over RCCL, one GPU each
+    (distributed.ShardedZeroSpan: one all-gather of [4N + 128W] per step + ksa_merge_gathered_dev).  Every rank must end
+    with the state of ONE engine that ran the whole run, the same bits on every rank.  Skipped on the one-GPU box."""
+    import socket
+    import torch.multiprocessing as mp
+    torch = torch_cuda
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL with N > 1 ranks)")
+    n, full, fpr = 1024, 8192, 150
+    one = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=128, max_frames=fpr * world)
+    for step in range(2):
+        x = orc.synth_iq(full * fpr * world, 900 + step).astype(np.complex64).reshape(world * fpr, full)
+        one.frames_dev(torch.view_as_real(torch.from_numpy(x)).cuda(), ksa.FMT_C64, fpr * world)
+    want = one.state()
+    one.close()
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_zerospan_nccl_rank, args=(world, port, out), nprocs=world, join=True)
+    first = np.load(out % 0)
+    for r in range(world):
+        got = np.load(out % r)
+        assert int(got["frames"]) == want["frames"] and int(got["hm_index"]) == want["hm_index"]
+        for k in CURVES + ("fftHM",):
+            assert_db(got[k], want[k], what="%s on rank %d" % (k, r))
+            assert np.array_equal(got[k], first[k]), "rank %d differs from rank 0 in %s" % (r, k)
