@@ -398,6 +398,14 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   unsigned long long t_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
 #endif
+#ifndef KSA_PF
+#define KSA_PF 1   // reuse path: the RM new samples of window k+1 are requested while window k is transformed (round 4: fits without
+                   // spilling since the transposed exchange layout; +1.9 % at config 2, +0.6 % at 75 % overlap, +1..3 % at N = 2048;
+                   // N = 1024 would spill 6-8 registers and large batches run the pair kernel there anyway)
+#endif
+  // (requesting the first window of the workgroup's NEXT frame before this frame's output stage, with LDS-only barriers
+  //  around the staging stores so that the loads stay in flight, measured 2.5 % SLOWER at config 2: profiles/r04_ab_prefetch_twiddles.txt)
+  constexpr bool PF = KSA_PF && RM > 0 && N >= 2048;
   for (int vf = blockIdx.x; vf < p.nframes * NP; vf += gridDim.x) {
     const int frame = vf / NP, part = vf - frame * NP;
     // this workgroup's contiguous share of the frame's windows (contiguous keeps the sample reuse valid)
@@ -413,12 +421,6 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       const bool active = S == 1 || k < k_hi;
       float2 v[16];
       float wpos[16];   // WIN_FUSED: the taps in the register order of v
-#ifndef KSA_PF
-#define KSA_PF 1   // reuse path: the RM new samples of window k+1 are requested while window k is transformed (round 4: fits without
-                   // spilling since the transposed exchange layout; +1.9 % at config 2, +0.6 % at 75 % overlap, +1..3 % at N = 2048;
-                   // N = 1024 would spill 6-8 registers and large batches run the pair kernel there anyway)
-#endif
-      constexpr bool PF = KSA_PF && RM > 0 && N >= 2048;
       if (PF) { if (rd == 0) issue_loads(frame, k, 0); }
       else if (active) issue_loads(frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
       if (active) {

@@ -245,7 +245,108 @@ float run(int wg_per_cu, int iters, float* out) {
   return ms;
 }
 
-int main() {
+// Round 4: P points per thread, T threads per transform, both exchanges moved in PIECES pieces through an LDS buffer of
+// T * P / PIECES elements (a transform that lives in registers and borrows LDS a piece at a time).  T == 64 is the
+// WAVE-PRIVATE transform of VERDICT r03 item 3: no s_barrier at all, the exchange is ordered by s_waitcnt alone.  Per
+// transform and thread: V v_fma on 16 chains in three blocks, GL streaming 8-byte loads, NS v_sqrt.
+template <int T, int P, int V, int PIECES, int GL, int NS>
+__global__ __launch_bounds__(T) void pieces(float* out, const float2* __restrict__ src, long long nsrc, int iters) {
+  extern __shared__ float2 lds[];
+  const int tid = threadIdx.x;
+  constexpr int Q = P / PIECES;
+  float a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = tid * 0.001f + i;
+  float2 r[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) r[i] = make_float2(tid + i, tid - i);
+  const float c0 = 0.999f, c1 = 0.001f;
+  const long long mask = nsrc - 1;
+  long long pos = ((long long)blockIdx.x * T + tid) & mask;
+  for (int it = 0; it < iters; ++it) {
+    float2 g[GL > 0 ? GL : 1];
+#pragma unroll
+    for (int q = 0; q < GL; ++q) g[q] = src[(pos + (long long)q * T) & mask];
+    pos = (pos + (long long)gridDim.x * T * GL) & mask;
+#pragma unroll
+    for (int q = 0; q < GL; ++q) a[q % 16] += g[q].x * g[q].y;
+#pragma unroll
+    for (int v = 0; v < V / 3; ++v) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[v % 16]) : "v"(c0), "v"(c1));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int pc = 0; pc < PIECES; ++pc) {
+        if (T > 64) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < Q; ++s) lds[s * (T + 2) + tid] = r[pc * Q + s];                 // transposed layout: conflict free
+        if (T > 64) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < Q; ++s) r[pc * Q + s] = lds[(tid % Q) * (T + 2) + tid / Q + (T / Q) * s];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int v = 0; v < V / 3; ++v) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[v % 16]) : "v"(c0), "v"(c1));
+    }
+#pragma unroll
+    for (int t = 0; t < NS; ++t) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[t % 16]));
+  }
+  float acc = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc += a[i];
+#pragma unroll
+  for (int i = 0; i < P; ++i) acc += r[i].x + r[i].y;
+  if (acc == 12345.678f) out[tid] = acc;
+}
+
+template <int T, int P, int V, int PIECES, int GL, int NS>
+float run_pieces(int wg_per_cu, int lds_bytes, int iters, float* out, const float2* src, long long nsrc) {
+  auto k = pieces<T, P, V, PIECES, GL, NS>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  int occ = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, T, lds_bytes);
+  hipFuncAttributes at;
+  hipFuncGetAttributes(&at, reinterpret_cast<const void*>(k));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int grid = 256 * wg_per_cu;
+  k<<<grid, T, lds_bytes>>>(out, src, nsrc, 10);
+  hipEventRecord(e0);
+  k<<<grid, T, lds_bytes>>>(out, src, nsrc, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("[%d VGPRs, occupancy %d WG/CU, asked %d] ", at.numRegs, occ, wg_per_cu);
+  return ms * 1e3f / iters / wg_per_cu;   // us per transform per CU
+}
+
+int main_r4(float* out, const float2* src, long long nsrc) {
+  const int it = 3000;
+  printf("round 4 shapes, us per transform per CU (N = 4096 unless stated; the real kernel: 1.42 after round 4, 1.50 before):\n");
+  printf("  4 waves x 16 points, 600 fma, 8 loads, 16 sqrt, whole exchanges, 3 WG/CU (49 KB)   : %.3f\n", run_pieces<256, 16, 600, 1, 8, 16>(3, 49 * 1024, it, out, src, nsrc));
+  printf("  wave-private: 1 wave x 64 points, 2400 fma, 32 loads, 64 sqrt, whole exchanges, 4 WG/CU (34 KB each)      : %.3f\n", run_pieces<64, 64, 2400, 1, 32, 64>(4, 34 * 1024, it / 2, out, src, nsrc));
+  printf("  wave-private, exchanges in 4 pieces through 8.5 KB, 8 WG/CU (2 waves per SIMD)                            : %.3f\n", run_pieces<64, 64, 2400, 4, 32, 64>(8, 9 * 1024, it / 2, out, src, nsrc));
+  printf("  wave-private, exchanges in 4 pieces, 12 WG/CU (3 waves per SIMD if the registers allow)                   : %.3f\n", run_pieces<64, 64, 2400, 4, 32, 64>(12, 9 * 1024, it / 2, out, src, nsrc));
+  printf("  2 waves x 32 points, 1200 fma, 16 loads, 32 sqrt, whole exchanges, 4 WG/CU (34 KB)                        : %.3f\n", run_pieces<128, 32, 1200, 1, 16, 32>(4, 34 * 1024, it / 2, out, src, nsrc));
+  printf("  2 waves x 32 points, exchanges in 2 pieces through 17 KB, 6 WG/CU                                         : %.3f\n", run_pieces<128, 32, 1200, 2, 16, 32>(6, 18 * 1024, it / 2, out, src, nsrc));
+  printf("N = 16384 (config 3; the real kernel: 8.0 us per window per CU):\n");
+  printf("  today: 8 waves x 32 points, 1632 fma, 64 loads, 32 sqrt, whole exchanges, 1 WG/CU (135 KB)                : %.3f\n", run_pieces<512, 32, 1632, 1, 64, 32>(1, 135 * 1024, it / 4, out, src, nsrc));
+  printf("  4 waves x 64 points, 3264 fma, 128 loads, 64 sqrt, exchanges in 2 pieces through 66 KB, 2 WG/CU           : %.3f\n", run_pieces<256, 64, 3264, 2, 128, 64>(2, 67 * 1024, it / 4, out, src, nsrc));
+  printf("  4 waves x 64 points, exchanges in 4 pieces through 33 KB, 2 WG/CU                                         : %.3f\n", run_pieces<256, 64, 3264, 4, 128, 64>(2, 34 * 1024, it / 4, out, src, nsrc));
+  printf("  8 waves x 32 points, exchanges in 2 pieces through 66 KB, 2 WG/CU (needs 128 VGPRs)                       : %.3f\n", run_pieces<512, 32, 1632, 2, 64, 32>(2, 67 * 1024, it / 4, out, src, nsrc));
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'r') {
+    float* out;
+    hipMalloc(&out, 4096);
+    float2* src;
+    const long long nsrc = 1ll << 28;
+    hipMalloc(&src, nsrc * 8);
+    hipMemset(src, 0, nsrc * 8);
+    return main_r4(out, src, nsrc);
+  }
   float* out;
   hipMalloc(&out, 4096);
   const int iters = 20000;
