@@ -91,6 +91,7 @@ struct ksa_engine {
   int* d_starts = nullptr;
   int* d_start_last = nullptr;  // RAW mode: the last window only
   float* d_window = nullptr;
+  float* d_window32 = nullptr;  // 32-point plan: the same taps as [8][N/32][4] (16-byte tap loads, ksa_kernels32.hpp)
   float2* d_tw_mid = nullptr;
   float2* d_tw_last = nullptr;
   float* d_adj = nullptr;       // zeroSpan Fft.Adj or null
@@ -461,7 +462,11 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
   const bool raw = c.cumu_mode == KSA_CUMU_RAW;
   p.nwin = raw ? 1 : c.num_windows;            // RAW keeps the last window only (K:135-136)
   p.starts = raw ? e->d_start_last : e->d_starts;
+#if defined(KSA32_TAPS_X4) && !KSA32_TAPS_X4
   p.window = e->d_window;
+#else
+  p.window = (e->plan32 && e->path == 0) ? e->d_window32 : e->d_window;
+#endif
   p.tw_mid = e->d_tw_mid;
   p.tw_last = e->d_tw_last;
   p.scale = (float)c.mag_scale;
@@ -725,6 +730,16 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
       }
       pcur *= pt;
     }
+    if (e->plan32) {
+      // taps (or, behind a first stage, the all-ones table) in the 32-point kernel's load order: [q4][l][j] = w[l + L*(4*q4 + j)]
+      const int lth = sn / 32;
+      std::vector<float> w32((size_t)sn);
+      for (int q4 = 0; q4 < 8; ++q4)
+        for (int l = 0; l < lth; ++l)
+          for (int j = 0; j < 4; ++j)
+            w32[((size_t)q4 * lth + l) * 4 + j] = e->path == 0 ? cfg->window[l + lth * (4 * q4 + j)] : 1.0f;
+      if ((rc = upload(&e->d_window32, w32.data(), w32.size()))) return bail(rc);
+    }
     if ((rc = upload(&e->d_tw_mid, mid.data(), mid.size()))) return bail(rc);
     if ((rc = upload(&e->d_tw_last, last.data(), last.size()))) return bail(rc);
     // constant hop of 1/2 or 1/4 of the transform: raw samples are carried over in registers
@@ -809,7 +824,7 @@ void ksa_destroy(ksa_engine* e) {
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (hipEvent_t ev : {e->ev_ready, e->ev_copied, e->ev_stream}) if (ev) hipEventDestroy(ev);
   void* ptrs[] = {e->d_gather, e->d_scan_stage, e->d_scan_rows, e->d_scan_halo, e->d_scan_send,
-                  e->d_starts, e->d_start_last, e->d_window, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
+                  e->d_starts, e->d_start_last, e->d_window, e->d_window32, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
                   e->d_iq_stage, e->d_frames, e->d_part, e->d_xchg, e->d_state, e->d_scan_state, e->d_scan_hm,
                   e->d_levels, e->d_parts, e->d_highs, e->d_scan_avg_rows, e->d_dif_tw, e->d_dif_z, e->d_dif_y, e->d_ones, e->d_starts_b};
   for (void* p : ptrs) if (p) hipFree(p);

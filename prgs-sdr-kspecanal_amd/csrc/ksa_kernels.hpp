@@ -75,8 +75,19 @@ __device__ __forceinline__ float out_db(float lin, int out_mode, float gain, flo
 // LogNoGain / Clip2MinAmp, store, waterfall cell max.  red = [S][N] floats in LDS (natural bin order).
 // Each thread takes 4 consecutive bins per step: one ds_read_b128, one 16-byte store, and the
 // waterfall cell (g = N/W consecutive bins) needs log2(g/4) shuffle steps instead of log2(g).
+// red row stride of slot s (floats).  N = 32 / 64 hold 32 / 16 transforms per wave and their unskewed rows (stride = 0 mod 32
+// banks) made every staging store 16- / 8-way conflicted (25 % of config 4's LDS cycles): rows skewed by 4 floats (16-byte
+// alignment kept) spread the 32 lanes of a store over the banks.  Measured on one box (15 windows per frame): N = 64 +6 %,
+// N = 32 +20 %; N = 16 / 128 / 256 -2 ... +1 % (noise or worse), so those keep the plain stride; config 4 (71 windows) +0.3 %.
+#ifndef KSA_RED_SKEW
+#define KSA_RED_SKEW 1
+#endif
+template <int N, int S>
+struct RedStride { static constexpr int value = (KSA_RED_SKEW && (N == 32 || N == 64)) ? N + 4 : N; };
+
 template <int N, int T, int S>
 __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, int frame, int tid) {
+  constexpr int RS = RedStride<N, S>::value;
   const int g = p.hm_w > 0 ? N / p.hm_w : 0;  // bins per waterfall cell
   const bool hm_fast = g > 0 && g <= 256 && g <= 4 * T;
   float* const orow = p.out + (long long)frame * N;
@@ -90,7 +101,7 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
     if constexpr (S > 1) {
 #pragma unroll 1
       for (int s2 = 1; s2 < S; ++s2) {
-        const float4 x = red4[s2 * (N / 4) + q];
+        const float4 x = red4[s2 * (RS / 4) + q];
         if (p.cumu == CUMU_AVG) { r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
         else if (p.cumu == CUMU_MAX) { r.x = nan_max(r.x, x.x); r.y = nan_max(r.y, x.y); r.z = nan_max(r.z, x.z); r.w = nan_max(r.w, x.w); }
         else { r.x = nan_min(r.x, x.x); r.y = nan_min(r.y, x.y); r.z = nan_min(r.z, x.z); r.w = nan_min(r.w, x.w); }
@@ -112,7 +123,7 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
       }
       // the cell maximum is np.max (K:195 through K:480): a NaN bin -- -inf minus a -inf baseline, K:405 -- makes the cell NaN
       if (!hm_fast) {
-        *reinterpret_cast<float4*>(red + S * N + sh) = make_float4(o[0], o[1], o[2], o[3]);  // second plane
+        *reinterpret_cast<float4*>(red + S * RS + sh) = make_float4(o[0], o[1], o[2], o[3]);  // second plane
       } else if (g == 1) {
         if (hm_row) *reinterpret_cast<float4*>(hm_row + sh) = make_float4(o[0], o[1], o[2], o[3]);
         if (hm_ring) *reinterpret_cast<float4*>(hm_ring + sh) = make_float4(o[0], o[1], o[2], o[3]);
@@ -137,7 +148,7 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
   }
   if (g > 0 && !hm_fast) {
     __syncthreads();
-    const float* hmbuf = red + S * N;
+    const float* hmbuf = red + S * RS;
 #pragma unroll 1
     for (int cell = tid; cell < p.hm_w; cell += T) {
       float hv = hmbuf[cell * g];
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
     float* const red = reinterpret_cast<float*>(lds);  // [S][N] floats, inside the data region
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) red[slot * N + l + L * perm<16>(i)] = acc[i];
+    for (int i = 0; i < 16; ++i) red[slot * RedStride<N, S>::value + l + L * perm<16>(i)] = acc[i];
     __syncthreads();
 #ifdef KSA_ABL_NOFIN   // timing-only ablation build: one store per thread keeps the fold alive
     if (red[tid] == 123.456f) p.out[tid] = red[tid];
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
         float4 r = red4[q];
         if constexpr (S > 1) {
           for (int s2 = 1; s2 < S; ++s2) {
-            const float4 x = red4[s2 * (N / 4) + q];
+            const float4 x = red4[s2 * (RedStride<N, S>::value / 4) + q];
             if (p.cumu == CUMU_AVG) { r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
             else if (p.cumu == CUMU_MAX) { r.x = nan_max(r.x, x.x); r.y = nan_max(r.y, x.y); r.z = nan_max(r.z, x.z); r.w = nan_max(r.w, x.w); }
             else { r.x = nan_min(r.x, x.x); r.y = nan_min(r.y, x.y); r.z = nan_min(r.z, x.z); r.w = nan_min(r.w, x.w); }

@@ -113,15 +113,34 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
   typedef typename std::conditional<FMT == FMT_C64, u32x2, unsigned short>::type raw_t;
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.window), 0, N * 4, 0x00020000);
   const auto twrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.tw_last), 0, 30 * L * 8, 0x00020000);
+  // Taps of the thread's 32 samples l + L*q.  The host hands this kernel the window table re-ordered as [8][L][4]
+  // (element (q4, l, j) = w[l + L*(4*q4 + j)]): eight 16-byte loads per window, each wave-instruction one contiguous KiB,
+  // instead of thirty-two 4-byte ones (round 4: the kernel issues 40 instead of 64 vector-memory instructions per window).
   float win[32];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef KSA32_TAPS_X4
+#define KSA32_TAPS_X4 1   // 0 (A/B builds, with the natural-order table): thirty-two 4-byte tap loads
+#endif
   auto load_taps = [&]() {
+#if !KSA32_TAPS_X4
 #pragma unroll
     for (int q = 0; q < 32; ++q)
-#ifdef KSA32_ABL_NOLOAD
-      win[q] = (float)(l + q) * p.u8_inv_scale;
-#else
       win[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, l * 4, L * q * 4, 0)) * (FMT == FMT_U8 ? p.u8_inv_scale : 1.0f);
+    return;
 #endif
+#pragma unroll
+    for (int q4 = 0; q4 < 8; ++q4) {
+#ifdef KSA32_ABL_NOLOAD
+      for (int j = 0; j < 4; ++j) win[4 * q4 + j] = (float)(l + 4 * q4 + j) * p.u8_inv_scale;
+#else
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, l * 16, q4 * L * 16, 0);
+      const float sc = FMT == FMT_U8 ? p.u8_inv_scale : 1.0f;
+      win[4 * q4 + 0] = __uint_as_float(w.x) * sc;
+      win[4 * q4 + 1] = __uint_as_float(w.y) * sc;
+      win[4 * q4 + 2] = __uint_as_float(w.z) * sc;
+      win[4 * q4 + 3] = __uint_as_float(w.w) * sc;
+#endif
+    }
   };
   if constexpr (KSA32_WIN_REGS) load_taps();
 

@@ -72,12 +72,13 @@ if dom and bench:
         ent["lds_insts_per_step"] = sum(c["SQ_INSTS_LDS"] * c["launches_pmc_sq"] for c in sq) / steps_in_pmc_run
         ent["lds_wait_ratio"] = (sum(c.get("SQ_WAIT_INST_LDS", 0.0) * c["launches_pmc_sq2"] for c in sq) /
                                  max(1.0, sum(c.get("SQ_WAVE_CYCLES", 0.0) * c["launches_pmc_sq"] for c in sq)))
-        # shader clock held during the stage: cycles / time of the same kernels in the --stats pass
+        # shader clock held during the stage: the counter pass's own cycles over its own kernel durations
         try:
-            ns = {}
-            for r in csv.DictReader(open(os.path.join(dst, tag + "_kernel_stats.csv"))):
-                ns[r["Name"].split("(")[0][:70]] = float(r["AverageNs"])
-            t = sum(ns[k] * c["launches_pmc_sq"] for k, c in dom.items() if k in ns and c in sq)
+            tr = glob.glob(os.path.join(src, "pmc_sq", "*", "*_kernel_trace.csv"))[0]
+            dur = collections.defaultdict(float)
+            for r in csv.DictReader(open(tr)):
+                dur[r["Kernel_Name"].split("(")[0][:70]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            t = sum(dur[k] for k, c in dom.items() if c in sq)
             if t > 0:
                 ent["shader_clock_ghz"] = cyc / t
         except Exception:
