@@ -478,3 +478,26 @@ def test_rccl_merge_path_world_device_count(ksa, torch_cuda, tmp_path):
         for k in CURVES + ("fftHM",):
             assert_db(got[k], want[k], what="%s on rank %d" % (k, r))
             assert np.array_equal(got[k], first[k]), "rank %d differs from rank 0 in %s" % (r, k)
+
+
+def test_bench_under_torch_distributed_run_launcher():
+    """The driver's exact command shape for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- rehearsed with two gloo ranks on this
+    GPU: rank 0 prints exactly one JSON line carrying the N > 1 fields."""
+    import socket
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ, KSA_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--frames", "512", "--no-cpu"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["baseline_config"] == 2
+    assert d["ranks"]["world_size"] == 2 and d["state_identical_across_ranks"] is True and d["strong"]["frames_per_gpu_per_step"] == 256
