@@ -350,19 +350,20 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
       for (int e = 0; e < 6; ++e) twl[e] = p.tw_last[rows[e] * P::P_LAST + l];
     }
   }
-  if constexpr (P::MID > 0) {
-    for (int i = tid; i < P::MID; i += T) tw_lds[i] = p.tw_mid[i];
-  }
   // M == 3: the 15 folded middle-pass twiddles of a thread (they depend on l mod R0 only) live in VGPRs as well -- the
   // transposed exchange layout freed ~30 registers (136 instead of 168 at N = 4096), which is exactly what they need.
   // Measured at config 2 on one box: re-read from LDS per window 5.76 ms, in VGPRs 5.62 ms, with the prefetch below 5.51 ms.
+  // (M > 3, experiments builds only, keeps the tables of its middle passes in LDS.)
 #ifndef KSA_TWM_REGS
 #define KSA_TWM_REGS 1
 #endif
+  constexpr bool TWM_REGS = KSA_TWM_REGS && M == 3 && FUSED;
   float2 twm[15];
-  if constexpr (KSA_TWM_REGS && M == 3 && FUSED) {
+  if constexpr (TWM_REGS) {
 #pragma unroll
     for (int e = 0; e < 15; ++e) twm[e] = p.tw_mid[e * R0 + (l & (R0 - 1))];
+  } else if constexpr (P::MID > 0) {
+    for (int i = tid; i < P::MID; i += T) tw_lds[i] = p.tw_mid[i];
   }
 
   if constexpr (WIN_LDS) __syncthreads();   // taps are read before the first exchange barrier
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
             }
             if (s < M - 1) {
               const float2* tw = tw_lds + tw_off + (l & (pp - 1));
-              if constexpr (KSA_TWM_REGS && M == 3 && FUSED) {
+              if constexpr (TWM_REGS) {
                 dft16_fused(v, reinterpret_cast<const float2(&)[15]>(twm));
               } else if constexpr (FUSED) {
                 float2 tm[15];
