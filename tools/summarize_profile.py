@@ -16,12 +16,14 @@ tag = sys.argv[1]
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)   # (gpurun merges every call's files into the same directories)
+shutil.copy(newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), os.path.join(dst, tag + "_kernel_stats.csv"))
 out = collections.defaultdict(dict)
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     fs = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     if not fs:
         continue
+    fs = [max(fs, key=os.path.getmtime)]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
         agg[(r["Kernel_Name"].split("(")[0][:70], r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -74,7 +76,7 @@ if dom and bench:
                                  max(1.0, sum(c.get("SQ_WAVE_CYCLES", 0.0) * c["launches_pmc_sq"] for c in sq)))
         # shader clock held during the stage: the counter pass's own cycles over its own kernel durations
         try:
-            tr = glob.glob(os.path.join(src, "pmc_sq", "*", "*_kernel_trace.csv"))[0]
+            tr = newest(os.path.join(src, "pmc_sq", "*", "*_kernel_trace.csv"))
             dur = collections.defaultdict(float)
             for r in csv.DictReader(open(tr)):
                 dur[r["Kernel_Name"].split("(")[0][:70]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
