@@ -490,8 +490,10 @@ def _handoff(d, eng, freqs, scan=False):
             if d[flag]:
                 d["AxLevels"].plot(xs, lv[row], colour)
     if last is not None:
-        marked = [(float(xs[i]), float(v)) for i, v in zip(idx, lvl)] if want_marks else []
-        _show_highs(d, marked)
+        if want_marks:
+            _show_highs(d, [(float(xs[i]), float(v)) for i, v in zip(idx, lvl)])
+        else:     # more markers than the device kernel returns (64), or a one-point curve: the host walk over the decimated curve
+            plot_highs(d, xs, lv[{"cur": 0, "max": 1, "min": 2, "avg": 3}[last]])
 
 
 def _show_highs(d, marked):
