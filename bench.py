@@ -218,6 +218,7 @@ def spawn_ranks(n):
     sys.stdout.flush()
 
 
+OVERLAP_DEFAULT = 0             # decided by the A/B of profiles/r05_ab_accum_overlap.txt
 SECONDARY_BUDGET_S = 150.0      # all side runs together; the driver's limit for the whole bench is 600 s
 
 
@@ -230,28 +231,33 @@ def secondary_configs(fmt, budget_s=SECONDARY_BUDGET_S):
     is recorded as skipped)."""
     res = {}
     t_end = time.monotonic() + budget_s
-    for k in (3, 4, 5):
+    # "2:u8": the headline geometry on the dongle's native uint8 I,Q (SURVEY 8 row A0: the unpack (b - 127.5) / 127.5 runs in the
+    # kernel's load stage; algorithmic bytes with s = 2 bytes per sample) -- only when the headline itself ran complex64
+    runs = ([("2:u8", 2, "u8")] if fmt == "c64" else []) + [(str(k), k, fmt) for k in (3, 4, 5)]
+    for key, k, f in runs:
         left = t_end - time.monotonic()
         if left < 15.0:
-            res[str(k)] = {"skipped": "side-run budget of %.0f s used up" % budget_s}
+            res[key] = {"skipped": "side-run budget of %.0f s used up" % budget_s}
             continue
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(k), "--fmt", fmt, "--steps", "10",
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(k), "--fmt", f, "--steps", "10",
                                 "--warmup", "2", "--no-cpu", "--no-secondary"], capture_output=True, text=True, timeout=left)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:
-                res[str(k)] = {"error": (r.stderr or "no output")[-300:]}
+                res[key] = {"error": (r.stderr or "no output")[-300:]}
                 continue
             d = json.loads(line[-1])
             rf = d["roofline"]
-            res[str(k)] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                           "msamples_per_s": d["msamples_per_s"], "steps": d["steps"], "kernel": rf["kernel"],
-                           "avg_kernel_ms": rf["avg_kernel_ms"], "bound": rf["bound"], "limiter": rf["limiter"],
-                           "frac": rf["frac"], "frac_step": rf["frac_step"], "flop_frac": rf["flop_frac"],
-                           "lds_frac": rf["lds_frac"], "valu_issue_frac": rf["valu_issue_frac"],
-                           "traffic": rf["traffic"], "traffic_over_algorithmic": rf["traffic_over_algorithmic"]}
+            res[key] = {"workload": d["config"]["workload"], "input": d["config"]["input"], "value": d["value"], "unit": d["unit"],
+                        "ms_per_step": d["ms_per_step"], "msamples_per_s": d["msamples_per_s"], "steps": d["steps"], "kernel": rf["kernel"],
+                        "avg_kernel_ms": rf["avg_kernel_ms"], "bound": rf["bound"], "limiter": rf["limiter"],
+                        "algorithmic_bytes_per_unit": rf["algorithmic_bytes_per_unit"],
+                        "frac": rf["frac"], "frac_step": rf["frac_step"], "flop_frac": rf["flop_frac"],
+                        "flop_frac_at_clock": rf["flop_frac_at_clock"], "shader_clock_ghz_live": rf["shader_clock_ghz_live"],
+                        "lds_frac": rf["lds_frac"], "valu_issue_frac": rf["valu_issue_frac"],
+                        "traffic": rf["traffic"], "traffic_over_algorithmic": rf["traffic_over_algorithmic"]}
         except Exception as ex:      # a failing side run must never take the headline line with it
-            res[str(k)] = {"error": repr(ex)[:300]}
+            res[key] = {"error": repr(ex)[:300]}
     return res
 
 
@@ -279,21 +285,39 @@ def pmc_record(key):
     return {}
 
 
-# What binds each configuration, as the counters of profiles/r0N_c*_pmc.json show it: `bound` names the
-# resource, `limiter` says it in a sentence.  The north star prices every configuration against HBM (`frac`); the fp32
-# (`flop_frac`), VALU-issue and LDS-array fractions stand beside it.
-BOUND = {
-    2: ("hbm", "priced against HBM as the north star asks (traffic = 1.00x algorithmic); what actually limits it is VALU issue "
-               "(~0.43 of the issue slots) and the LDS exchange (~0.45 of the LDS-array cycles) running in series at 3 waves per SIMD"),
-    3: ("valu", "90 % window overlap: every sample is transformed ten times, VALU alone is 4.9 of 8.0 us per window at one workgroup "
-                "(135 KB of LDS) per CU; HBM sees 0.06 of its peak"),
-    4: ("valu", "90 % window overlap at N = 64: 16 transforms per wave, VALU-issue bound (no pipe above 40 %); HBM sees 0.13 of its peak"),
-    5: ("hbm (Z round trip)", "two streaming passes over the first-stage scratch Z: 7.9x the algorithmic bytes move, both stages run at the "
-                              "4.7-5.0 TB/s a mixed read/write stream reaches"),
-}
+# What binds each configuration: `bound` names the resource, `limiter` says it in a sentence.  The north star
+# prices every configuration against HBM (`frac`); the fp32 (`flop_frac`), VALU-issue and LDS-array fractions stand beside it.
+# ONE source of truth: every decimal number in the sentence is formatted from a field of the same roofline block
+# (tests/test_host_cli.py::test_limiter_quotes_its_own_fields), so the prose cannot go stale against the counters.
+BOUND = {2: "hbm", 3: "valu", 4: "valu", 5: "hbm (Z round trip)"}
+NOMINAL_CLOCK_GHZ = 2.4    # the clock the 157.3 TFLOP/s fp32 peak is quoted at (MI355X_MICROARCH.md)
+
+
+def limiter_sentence(config, rf):
+    """rf: the roofline block (frac, flop_frac and, when the stored counter passes match the kernel sources, valu_issue_frac /
+    lds_frac / traffic_over_algorithmic).  Numbers are quoted with two decimals, straight from those fields."""
+    have = all(rf.get(k) is not None for k in ("valu_issue_frac", "lds_frac", "traffic_over_algorithmic"))
+    pipes = ("VALU issue %.2f of the issue slots, LDS array %.2f of its cycles, counter traffic %.2fx the algorithmic bytes"
+             % (rf["valu_issue_frac"], rf["lds_frac"], rf["traffic_over_algorithmic"])) if have else \
+        "counters not available for this source hash (re-run tools/profile_bench.sh)"
+    head = {
+        2: "priced against HBM as the north star asks (%.2f of its peak, fp32 %.2f of the vector peak); what limits it is VALU issue and the "
+           "LDS exchanges running in series at 3 waves per SIMD",
+        3: "90 % window overlap: every sample is transformed ten times, one workgroup of 135 KB of LDS per CU at 2 waves per SIMD; HBM sees "
+           "%.2f of its peak, fp32 %.2f of the vector peak",
+        4: "90 % window overlap at N = 64: 16 transforms per wave, issue-latency bound; HBM sees %.2f of its peak, fp32 %.2f of the vector peak",
+        5: "two streaming passes over the first-stage scratch Z: HBM sees %.2f of its peak in algorithmic bytes, fp32 %.2f of the vector peak",
+    }[config] % (rf["frac"], rf["flop_frac"])
+    return head + "; " + pipes
 
 
 # ------------------------------------------------------------------------------------------- topology / state proofs
+def backend_name(backend):
+    """What the record calls the collective backend actually in use: torch's "nccl" IS RCCL on ROCm; gloo (the rehearsals
+    of the launch path on shared devices) stages through the host."""
+    return "RCCL (torch.distributed nccl backend)" if backend == "nccl" else "%s (host-staged; rehearsal backend)" % backend
+
+
 def device_identity(torch, local):
     """What tells two GPUs apart: ordinal, marketing name, PCI bus id and uuid (whatever this torch build exposes)."""
     pr = torch.cuda.get_device_properties(local)
@@ -350,6 +374,9 @@ def parse_args():
                     help="headline run on one GPU: skip the short runs of the other BASELINE configurations (3, 4, 5)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1, zeroSpan only: run the multi-GPU merge path on a one-rank group, to price its fixed cost")
+    ap.add_argument("--overlap", type=int, choices=(0, 1), default=OVERLAP_DEFAULT,
+                    help="zeroSpan, one GPU: 1 = overlap mode (ksa_set_overlap): the accumulate + commit of step i runs on the engine's "
+                         "side stream under the spectrum stage of step i+1, the per-frame dB rows alternate between two buffers")
     ap.add_argument("--inprocess", action="store_true",
                     help="ONE process, --gpus engines placed on the visible devices (engine r on device r %% device_count), merged by "
                          "ksa_allreduce_state / ksa_scan_allstitch: the torch-free multi-GPU form (no RCCL)")
@@ -377,8 +404,10 @@ def roofline_block(cfg, args, eng, units_per_step, kern_ms, launches, step_s):
         kernel = "ksa::spectrum_kernel<%d,%s>" % (n, args.fmt)
     rec = pmc_record("%d:%s:%d" % (args.config, args.fmt, units_per_step))
     traffic = rec.get("hbm_bytes_per_launch")
-    bound, limiter = BOUND[args.config]
-    return {"bound": bound, "limiter": limiter, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # shader clock held under the profiled spectrum stages of THIS run (stamp kernels around each stage: ksa_prof_clock)
+    clock_live, clock_samples = eng.prof_clock()
+    clock = clock_live or rec.get("shader_clock_ghz")
+    rf = {"bound": BOUND[args.config], "limiter": None, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": rec.get("source"),
             "traffic_note": ("counter figures (traffic = 2*FETCH_SIZE + WRITE_SIZE per step; lds_frac = SQ_LDS_IDX_ACTIVE / CUs / kernel cycles; "
                              "valu_issue_frac = SQ_INSTS_VALU * 2 clk / SIMDs / kernel cycles; lds_conflict_ratio = SQ_LDS_BANK_CONFLICT / "
@@ -396,7 +425,14 @@ def roofline_block(cfg, args, eng, units_per_step, kern_ms, launches, step_s):
             "tflops": tflops, "flop_peak": FP32_PEAK_TFLOPS, "flop_frac": tflops / FP32_PEAK_TFLOPS,
             "lds_frac": rec.get("lds_frac"), "lds_conflict_ratio": rec.get("lds_conflict_ratio"),
             "valu_issue_frac": rec.get("valu_issue_frac"), "shader_clock_ghz": rec.get("shader_clock_ghz"),
+            # live: median over XCDs and launches of d(s_memtime) / d(s_memrealtime) x 100 MHz around each timed spectrum stage
+            "shader_clock_ghz_live": clock_live, "shader_clock_samples": clock_samples,
+            # the fp32 fraction of what the chip can issue at the clock it actually held (the peak is quoted at 2.4 GHz)
+            "flop_frac_at_clock": (tflops / (FP32_PEAK_TFLOPS * clock / NOMINAL_CLOCK_GHZ)) if clock else None,
+            "flop_frac_at_clock_source": ("shader_clock_ghz_live" if clock_live else "shader_clock_ghz (stored counter pass)") if clock else None,
             "threads": info["threads"], "lds_bytes": info["lds_bytes"], "vgprs": info["vgprs"], "grid": info["grid"]}
+    rf["limiter"] = limiter_sentence(args.config, rf)
+    return rf
 
 
 def main():
@@ -444,22 +480,33 @@ def main():
     resident_iq = lambda units: make_resident_iq(torch, orc, args, cfg, units, rank)
 
     strong_step = None
+    overlap = False
     if cfg["mode"] == "zerospan":
         frames = args.frames or cfg["frames"]
         units_per_step = frames                       # per rank
         iq = resident_iq(frames)
         eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=cfg["window"], gain=GAIN, xres=cfg["xres"],
                                  max_frames=frames, device=local, stream=stream)
-        cur_db = torch.empty((frames, n), dtype=torch.float32, device="cuda")
+        # overlap mode needs commit-at-once batches (one GPU, no collective); the dB rows of consecutive steps then go to
+        # two alternating buffers, so that step i+1 does not overwrite what step i's accumulate still reads
+        overlap = bool(args.overlap) and world == 1 and not args.force_collective
+        cur_dbs = [torch.empty((frames, n), dtype=torch.float32, device="cuda") for _ in range(2 if overlap else 1)]
+        cur_db = cur_dbs[0]
         hm_rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
         run = ksa_dist.ShardedZeroSpan(eng, rank, world, always_collective=args.force_collective)
-        step = lambda: run.step(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
+        if overlap:
+            eng.set_overlap(True)
+        flip = [0]
+
+        def step():
+            flip[0] ^= 1
+            run.step(iq, fmt, frames, cur_db=cur_dbs[flip[0] % len(cur_dbs)], hm_rows=hm_rows)
         if world > 1 and frames // world >= 1:
             fs = frames // world                      # the SAME job as one GPU's step, split over the ranks
             strong_step = (fs, lambda: run.step(iq, fmt, fs, cur_db=cur_db, hm_rows=hm_rows))
         sharding = "time-chunk"
-        collective = ("RCCL: 1 all-gather of [4N + 128W] floats per rank per step over %d ranks, merged by ksa_merge_gathered_dev"
-                      % world) if world > 1 else "none"
+        collective = ("%s: 1 all-gather of [4N + 128W] floats per rank per step over %d ranks, merged by ksa_merge_gathered_dev"
+                      % (backend_name(backend), world)) if world > 1 else "none"
         xb = (4 * n + 128 * eng.hm_width) * 4
         coll_bytes = {"allgather_send": xb, "allgather_recv": xb * (world - 1)} if world > 1 else {}
         scaling = "weak"                              # every GPU brings its own time chunk: work per GPU fixed
@@ -477,9 +524,9 @@ def main():
         run = ksa_dist.ShardedScan(eng, rank, world)
         step = lambda: run.run_passes(iq, fmt, steps, passes)
         sharding = "freq-band"
-        collective = ("RCCL: halo send/recv of the overlap part of 1 band per pass to the right neighbour + 1 all-gather of the "
+        collective = ("%s: halo send/recv of the overlap part of 1 band per pass to the right neighbour + 1 all-gather of the "
                       "partial waterfall rows [min(passes,128)][W] per step over %d ranks; curves stay sharded by stitched range"
-                      % world) if world > 1 else "none"
+                      % (backend_name(backend), world)) if world > 1 else "none"
         scaling = "strong"                            # the scan range is one fixed job split over the GPUs
         batch = {"passes_per_step": passes, "steps_per_pass": steps, "bands_on_rank0": mine, "total_entries": total}
 
@@ -548,12 +595,14 @@ def main():
             "config": dict({"workload": cfg["workload"], "baseline_config": args.config,
                             "input": "complex64" if args.fmt == "c64" else "uint8", "samples_per_unit": full,
                             "windows_per_unit": nwin, "sharding": sharding, "collective": collective,
+                            "accumulate_overlap": bool(cfg["mode"] == "zerospan" and overlap),
                             "collective_bytes_per_rank_per_step": coll_bytes}, **batch),
             "roofline": roofline_block(cfg, args, eng, units_per_step, kern_ms, launches, step_s),
         }
         if world > 1:
             out["ranks"] = ranks
             out.update(proof)
+            out["value_is_rehearsal"] = ranks["distinct_devices"] < world     # ranks share devices: `value` is NOT a throughput
             out["multi_gpu_note"] = ("%d rank processes over %s; %d distinct device(s) among them%s" % (
                 world, ranks["backend"], ranks["distinct_devices"],
                 "" if ranks["distinct_devices"] == world else " -- a functional REHEARSAL of the launch path on shared devices, not a scaling measurement"))
@@ -682,6 +731,7 @@ def main_inprocess(args):
            "ranks": {"backend": "inprocess (hipMemcpyPeerAsync + events)", "world_size": world, "rccl_version": None,
                      "distinct_devices": distinct, "visible_devices_rank0": ndev, "per_rank": idents},
            "state_identical_across_ranks": len(set(digests)) == 1, "state_sha256_rank0": digests[0],
+           "value_is_rehearsal": distinct < world,
            "multi_gpu_note": "%d engines on %d distinct device(s)%s" % (
                world, distinct, "" if distinct == world else " -- a functional REHEARSAL on shared devices, not a scaling measurement")}
     for eng in engines:

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (A/B runs of variant builds swap the file: tools/with_lib.sh).
 LIB_PATH = os.path.join(HERE, "libksa.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 HM_ROWS = 128
 CUMU = {"RAW": 0, "AVG": 1, "MAX": 2, "MIN": 3}
 FMT_C64, FMT_U8 = 0, 1
@@ -43,6 +43,7 @@ SIGNATURES = {
     "ksa_destroy": (None, [_P]),
     "ksa_set_stream": (C.c_int, [_P, _P]),
     "ksa_synchronize": (C.c_int, [_P]),
+    "ksa_set_overlap": (C.c_int, [_P, _I32]),
     "ksa_curscan_c64": (C.c_int, [_P, _P, _P]),
     "ksa_curscan_u8": (C.c_int, [_P, _P, _P]),
     "ksa_curscan_dev": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "ksa_host_free": (C.c_int, [_P]),
     "ksa_prof_enable": (C.c_int, [_P, _I32]),
     "ksa_prof_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    "ksa_prof_clock": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "ksa_kernel_info": (C.c_int, [_P] + [C.POINTER(_I32)] * 5),
 }
 

@@ -47,6 +47,29 @@ struct SpecParams {
   unsigned long long* dbg;  // diagnostic builds only (-DKSA_STAMPS): [grid][16] cycle sums; null otherwise
 };
 
+// Shader clock held under the spectrum stage (bench.py `shader_clock_ghz_live`, ksa_prof_clock): a stamp kernel of CLK_WGS
+// single-wave workgroups runs on the engine's stream directly before and directly after a PROFILED spectrum stage; each wave
+// reads s_memtime (shader cycles of its XCD) and s_memrealtime (the constant 100 MHz counter) and stores them under its XCD's
+// id.  The host takes d(memtime) / d(memrealtime) x 100 MHz per XCD and the median over the XCDs and launches
+// (MI355X_MICROARCH.md, 'DVFS give-back' item 6).  The spectrum kernels themselves carry NO stamp: their register files are
+// full, and two stamps inside spectrum_kernel<4096,c64,8,AVG> cost three more spilled VGPRs (2 -> 5; measured, removed).
+// The interval includes the two launch gaps (a few us next to the 5 ms of a config-2 launch).
+constexpr int CLK_WGS = 64;       // enough single-wave workgroups to land on every XCD
+constexpr int CLK_XCDS = 8;
+constexpr int CLK_SLOTS = 64;     // profiled launches whose stamps are kept (ring)
+// out = [which = 0 before | 1 after][xcd][2] = {memtime, memrealtime}; several waves of one XCD write the same slot, any of
+// them is as good as the other (they run within a microsecond of each other)
+__global__ __launch_bounds__(64) void clock_stamp_kernel(unsigned long long* out, int which) {
+  unsigned long long c, r;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r)::"memory");
+  const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & (CLK_XCDS - 1);   // HW_REG_XCC_ID[3:0]
+  if (threadIdx.x == 0) {
+    unsigned long long* o = out + ((long long)which * CLK_XCDS + xcc) * 2;
+    o[0] = c;
+    o[1] = r;
+  }
+}
+
 // 10*log10(x) - gain through the hardware log2 (v_log_f32, 1 ulp): 10*log10(2) * log2(x) - gain.  libm's log10f
 // costs ~12 more VALU instructions per bin (1.2 % of the config-2 kernel); 0 -> -inf and NaN -> NaN are kept,
 // denormal magnitudes (< 1.2e-38, below -380 dB) read as zero.

@@ -180,6 +180,11 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
     }                                                        \
   } while (0)
 
+#ifdef KSA_STAMPS   // diagnostic build: where a wave's time goes (segments named at the KSA_STAMP calls below)
+  unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
   for (int vf = blockIdx.x; vf < total; vf += gridDim.x) {
     const int frame = vf / NP;
     const int k_lo = k_lo_of(vf), k_hi = k_hi_of(vf);
@@ -205,12 +210,16 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
           v[q] = make_float2(((float)(x & 0xff) - p.u8_offset) * win[q], ((float)(x >> 8) - p.u8_offset) * win[q]);
         }
       }
+      KSA_STAMP(0);    // issue + wait for the 32 IQ loads and 8 tap loads, window multiply
       // ---- pass 0: radix 32, no twiddles; butterfly i = l, outputs to 32*l + t' ----------------------
       dft32(v);
+      KSA_STAMP(1);    // pass 0 butterflies
       lds_barrier();   // the previous window's (frame's) LDS reads are done
+      KSA_STAMP(2);    // barrier in front of exchange 1
 #pragma unroll
       for (int P0 = 0; P0 < 32; ++P0) K32_ST(my[pad32(l * 32 + perm32(P0))], v[P0]);
       lds_barrier();
+      KSA_STAMP(3);    // exchange 1: stores + barrier
       // ---- pass 1: p = 32, k = l mod 32 ---------------------------------------------------------------
 #pragma unroll
       for (int q = 0; q < 32; ++q) K32_LD(v[(q % B1) * R1 + q / B1], my[pad32(l + L * q)]);
@@ -222,6 +231,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
 #pragma unroll
           for (int e = 0; e < 15; ++e) { ta[e] = tw[(1 + e) * 32]; tb[e] = tw[(16 + e) * 32]; }
           dft32_fused(v, tw[0], ta, tb);
+          KSA_STAMP(4);  // exchange-1 reads, 31 twiddle reads, pass 1 butterflies
           lds_barrier();
           const int j = (l - kk) * 32 + kk;
 #pragma unroll
@@ -232,6 +242,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
           for (int e = 0; e < 15; ++e) tm[e] = tw[e * 32];
           dft16_fused_at<0>(v, tm);      // i = l      (k = l mod 32)
           dft16_fused_at<16>(v, tm);     // i = l + L  (L is a multiple of 32: same k)
+          KSA_STAMP(4);
           lds_barrier();
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
@@ -243,6 +254,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
       }
       PREFETCH_NEXT();   // v is dead (written to LDS): the landing registers are free from here to the next window's top
       lds_barrier();
+      KSA_STAMP(5);      // exchange 2: barrier, stores, barrier
       // ---- pass 2: radix 16, p = N/16, butterflies i = l + b*L with k = i, one after the other (16 live data
       //      registers instead of 32), each followed by |X| and the fold over this block's windows (K:391-395)
       const int cm = CM == 0 ? p.cumu : CM;
@@ -285,6 +297,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
           for (int i = 0; i < 16; ++i) acc[b * 16 + i] = nan_min(acc[b * 16 + i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
         }
       }
+      KSA_STAMP(6);      // exchange-2 reads, pass 2 (two radix-16 butterflies) and the fold
     }
 
     // ---- natural bin order through LDS, then the common output stage --------------------------------
@@ -301,7 +314,13 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
       for (int q = l; q < N / 4; q += T) dst[q] = red4[q];
     }
     // (the next frame's first exchange barrier orders these LDS reads before its writes)
+    KSA_STAMP(8);        // per-frame output stage
   }
+#ifdef KSA_STAMPS
+  if (p.dbg && (l & 63) == 0) {
+    for (int i = 0; i < 10; ++i) p.dbg[((long long)blockIdx.x * (T / 64) + l / 64) * 10 + i] = seg[i];
+  }
+#endif
 }
 
 #undef PREFETCH_NEXT

@@ -15,7 +15,9 @@ Deliberate differences: playback needs no SDR; in scan mo
 refreshed once per pass (the whole pass is one device call) instead of once per tuned band.
 Hand-off traffic: with a decimating pltCompress (AVG|MAX|MIN) a frame / pass brings back the four
 xRes-point Levels curves, the peak markers and the ONE new waterfall row (ksa_read_view, d['handoff.bytes']); the
-full-width d['Fft.*'] arrays are read from the device when a RAW / CONV plot needs them and once at the end of a run.
+full-width d['Fft.*'] arrays are read from the device when a RAW / CONV plot needs them and once at the end of a run:
+DURING such a run they are None / stale (the reference refreshes them after every frame, K:470-476) -- code that reads
+d['Fft.*'] between frames calls _materialize(d, d['ksa.engine'], scan) first.
 """
 import pickle
 import signal
@@ -467,8 +469,10 @@ def _handoff(d, eng, freqs, scan=False):
     for flag in ("bDataMax", "bDataMin", "bDataAvg", "bDataCur"):        # plotting order of K:489-503: the last one is marked
         if d[flag]:
             last = flag[5:].lower()
-    if d.get("Levels.key") != (id(freqs), d["xRes"]):
-        d["Levels.x"], d["Levels.key"] = _plotcompress(d, freqs, "AVG"), (id(freqs), d["xRes"])
+    # decimated x axis, cached by VALUE of the axis (an id() of a freed array can come back for a different axis)
+    key = (len(freqs), float(freqs[0]), float(freqs[-1]), d["xRes"])
+    if d.get("Levels.key") != key:
+        d["Levels.x"], d["Levels.key"] = _plotcompress(d, freqs, "AVG"), key
     xs = d["Levels.x"]
     count = d["pltHighsNumMarkers"]
     cell = (xs[-1] - xs[0]) / (len(xs) - 1) if len(xs) > 1 else 1.0

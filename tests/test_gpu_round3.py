@@ -357,8 +357,9 @@ def test_bench_headline_line_carries_the_secondary_configs():
     d = _bench(["--frames", "2048", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.3"], timeout=1200)
     assert d["config"]["baseline_config"] == 2 and d["n_gpus"] == 1
     sec = d["secondary_configs"]
-    assert sorted(sec) == ["3", "4", "5"]
-    for k, want in (("3", "fmScan"), ("4", "quickFullScan"), ("5", "65536")):
+    assert sorted(sec) == ["2:u8", "3", "4", "5"]
+    assert sec["2:u8"]["input"] == "uint8" and sec["2:u8"]["algorithmic_bytes_per_unit"] == 32768 * 2 + 4 * 4096 + 4 * 512   # s = 2
+    for k, want in (("2:u8", "fftSize=4096"), ("3", "fmScan"), ("4", "quickFullScan"), ("5", "65536")):
         assert "error" not in sec[k], sec[k]
         assert want in sec[k]["workload"] and sec[k]["value"] > 0 and 0 < sec[k]["frac"] < 1 and 0 < sec[k]["flop_frac"] < 1
     d2 = _bench(["--frames", "2048", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-secondary"])

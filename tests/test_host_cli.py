@@ -139,7 +139,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
     for name in declared:
         assert hasattr(pkg.lib, name)
-    assert pkg.lib.ksa_abi_version() == 3
+    abi = int(re.search(r"#define\s+KSA_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert pkg.lib.ksa_abi_version() == abi == lib.ABI_VERSION     # header, library and binding agree
     # without a GPU the library must fail loudly, not fall back
     import torch
     if not torch.cuda.is_available():
@@ -184,3 +185,152 @@ def test_data_2d_plotcompress_rows():
     assert k.data_2d_plotcompress(d, data, "RAW") is data
     hm = np.ones((128, 64)) * 3.9e-8                      # K:613: ones * minAmp4Clip
     assert np.array_equal(k.data_2d_plotcompress(d, hm), np.full((128, 8), 3.9e-8))
+
+
+# ------------------------------------------------------------------------------- INTEGRATION.md stays executable
+def integration_blocks():
+    """{section number: [source of every ```python block of that section]} of INTEGRATION.md."""
+    import re
+    text = open(os.path.join(os.path.dirname(GOLDEN), "..", "INTEGRATION.md")).read()
+    out, sec = {}, None
+    pos = 0
+    for m in re.finditer(r"^## (\w+)\.[^\n]*$|^```python\n(.*?)^```", text, flags=re.M | re.S):
+        if m.group(1) is not None:
+            sec = m.group(1)
+        else:
+            out.setdefault(sec, []).append(m.group(2))
+    return out
+
+
+def _ksa_calls(tree):
+    """(name, number of positional arguments or None when a *starred argument makes it unknowable) of every ksa.ksa_*(...) call,
+    plus every bare ksa.ksa_* attribute."""
+    import ast
+    calls, names = [], set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id == "ksa" and node.attr.startswith("ksa_"):
+            names.add(node.attr)
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and isinstance(node.func.value, ast.Name) \
+                and node.func.value.id == "ksa" and node.func.attr.startswith("ksa_"):
+            starred = any(isinstance(a, ast.Starred) for a in node.args)
+            calls.append((node.func.attr, None if starred else len(node.args)))
+    return calls, names
+
+
+def test_integration_doc_blocks_compile_and_match_the_binding():
+    """Every ```python block of INTEGRATION.md sections 2-5 is valid Python, names only entry points the library has
+    (_lib.SIGNATURES) with the right number of arguments, and its KsaConfig mirrors _lib.Config field for field; the ABI
+    handed to ksa_create comes from ksa_abi_version(), never from a literal; the ABI number and the entry-point count the text
+    quotes are the header's.  Bumping KSA_ABI_VERSION, adding an entry point or a config field without touching the document
+    turns this red."""
+    import ast
+    import ctypes as C
+    import re
+    load_pkg()
+    lib = __import__("importlib").import_module("prgs-sdr-kspecanal_amd._lib")
+    blocks = integration_blocks()
+    assert {"2", "3", "4", "5"} <= set(blocks), sorted(blocks)
+    seen_cfg = False
+    for sec in ("2", "3", "4", "5"):
+        for src in blocks[sec]:
+            tree = ast.parse(src, "INTEGRATION.md#%s" % sec)
+            calls, names = _ksa_calls(tree)
+            assert names, "section %s names no entry point" % sec
+            for name in names:
+                assert name in lib.SIGNATURES, "INTEGRATION.md section %s: %s is not an entry point of include/ksa.h" % (sec, name)
+            for name, nargs in calls:
+                if nargs is not None:
+                    assert nargs == len(lib.SIGNATURES[name][1]), "section %s: %s called with %d arguments, the ABI takes %d" % (
+                        sec, name, nargs, len(lib.SIGNATURES[name][1]))
+            for node in ast.walk(tree):
+                if isinstance(node, ast.ClassDef) and node.name == "KsaConfig":
+                    fields = [s for s in node.body if isinstance(s, ast.Assign) and s.targets[0].id == "_fields_"][0]
+                    got = eval(compile(ast.Expression(fields.value), "KsaConfig._fields_", "eval"), {"C": C})
+                    assert got == list(lib.Config._fields_), "KsaConfig in the document differs from ksa_config / _lib.Config"
+                    seen_cfg = True
+                if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "KsaConfig":
+                    first = node.args[0]
+                    assert isinstance(first, ast.Call) and ast.unparse(first.func) == "ksa.ksa_abi_version", \
+                        "abi_version must come from ksa.ksa_abi_version(), not from %s" % ast.unparse(first)
+                    assert len(node.args) == len(lib.Config._fields_)
+    assert seen_cfg
+    text = open(os.path.join(os.path.dirname(GOLDEN), "..", "INTEGRATION.md")).read()
+    hdr = open(os.path.join(os.path.dirname(GOLDEN), "..", "include", "ksa.h")).read()
+    abi = int(re.search(r"#define\s+KSA_ABI_VERSION\s+(\d+)", hdr).group(1))
+    quoted = re.search(r"`KSA_ABI_VERSION (\d+)` \((\d+) entry points", text)
+    assert quoted and int(quoted.group(1)) == abi == lib.ABI_VERSION, "INTEGRATION.md quotes another ABI version than include/ksa.h"
+    assert int(quoted.group(2)) == len(lib.SIGNATURES), "INTEGRATION.md quotes %s entry points, the header declares %d" % (
+        quoted.group(2), len(lib.SIGNATURES))
+
+
+def test_integration_doc_check_catches_a_stale_document():
+    """The checker itself: a block that passes a literal ABI, misspells an entry point or drops an argument is caught."""
+    import ast
+    lib = __import__("importlib").import_module("prgs-sdr-kspecanal_amd._lib")
+    calls, names = _ksa_calls(ast.parse("ksa.ksa_frame_c64(h)\nksa.ksa_nope(h)\nksa.ksa_read_state(h, *bufs)"))
+    assert ("ksa_frame_c64", 1) in calls and ("ksa_read_state", None) in calls and "ksa_nope" in names
+    assert "ksa_nope" not in lib.SIGNATURES and len(lib.SIGNATURES["ksa_frame_c64"][1]) == 2
+
+
+# ------------------------------------------------------------------------------- every entry point runs on its engine's device (ADVICE r04)
+def _c_functions(src):
+    """{name: body} of the functions defined at brace depth 0 of a C++ source (good enough for ksa_api.hip's extern "C" part)."""
+    import re
+    out = {}
+    for m in re.finditer(r"^(?:static\s+)?(?:int|void|const char\*)\s+(\w+)\s*\(([^)]*)\)\s*\{", src, flags=re.M):
+        depth, i = 1, m.end()
+        while depth and i < len(src):
+            depth += {"{": 1, "}": -1}.get(src[i], 0)
+            i += 1
+        out[m.group(1)] = (m.group(2), src[m.end():i])
+    return out
+
+
+def test_every_entry_point_that_touches_hip_selects_its_engines_device():
+    """include/ksa.h promises that every entry point selects its engine's device for its own duration and hands the caller's
+    current device back.  The default engine stream is the NULL stream -- "the null stream of the CURRENT device" -- so an
+    entry point that forgets (ksa_synchronize and ksa_prof_read did in round 4) silently works on another GPU.  Static check of
+    ksa_api.hip: every exported ksa_* with an engine (or engine array) parameter whose body issues a HIP call, a launch or one
+    of the helpers that do must hold a DeviceGuard.  (A one-GPU box cannot see the difference at run time.)"""
+    import re
+    root = os.path.join(os.path.dirname(GOLDEN), "..")
+    src = open(os.path.join(root, "prgs-sdr-kspecanal_amd", "csrc", "ksa_api.hip")).read()
+    ext = src[src.index('extern "C" {'):]
+    fns = _c_functions(ext)
+    hdr = open(os.path.join(root, "include", "ksa.h")).read()
+    exported = set(re.findall(r"\b(ksa_[a-z0-9_]+)\s*\(", hdr))
+    assert exported <= set(fns) | {"ksa_abi_version", "ksa_last_error"}, exported - set(fns)
+    helpers = r"run_spectrum|run_accumulate|do_commit|fill|scan_reset|join_side|levels_to_scratch|copy_ring_rows|scan_stitch|gather_all|upload|ensure|scan_spectra|copy_d2d|ensure_events"
+    touches = re.compile(r"\bhip[A-Z]\w*\s*\(|\bHIP_OK\b|hipLaunchKernelGGL|\b(?:%s)\s*\(" % helpers)
+    checked = 0
+    for name in sorted(exported & set(fns)):
+        params, body = fns[name]
+        if "ksa_engine" not in params or not touches.search(body):
+            continue
+        checked += 1
+        assert "DeviceGuard" in body, "%s touches HIP without a DeviceGuard" % name
+        # ... and selects the device itself or through a helper that does (scan_stitch, levels_to_scratch, check_handles' callers)
+        assert re.search(r"hipSetDevice\s*\(|scan_stitch\s*\(|levels_to_scratch\s*\(|gather_all\s*\(", body), "%s never selects its engine's device" % name
+    assert checked >= 25, checked
+    for name in ("curscan_host", "frame_host", "scan_pass_host"):          # the static bodies behind the _c64 / _u8 pairs
+        assert "DeviceGuard" in fns[name][1] and "hipSetDevice" in fns[name][1], name
+
+
+# ------------------------------------------------------------------------------- the bench record's limiter sentence (VERDICT r04 item 2)
+def test_limiter_quotes_its_own_fields():
+    """bench.limiter_sentence formats every decimal number it prints from the roofline block it is handed -- there is no
+    hard-coded counter figure left to go stale -- and says so when no counter record matches the kernel sources."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("ksa_bench", os.path.join(os.path.dirname(GOLDEN), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for cfg in (2, 3, 4, 5):
+        rf = {"frac": 0.4193, "flop_frac": 0.3361, "valu_issue_frac": 0.4916, "lds_frac": 0.3120, "traffic_over_algorithmic": 1.0003}
+        text = bench.limiter_sentence(cfg, rf)
+        got = sorted(float(t) for t in re.findall(r"(?<![\w.])\d+\.\d+", text))
+        assert got == sorted(round(v, 2) for v in rf.values()), (cfg, text)
+        bare = bench.limiter_sentence(cfg, {"frac": 0.07, "flop_frac": 0.29})
+        assert "counters not available" in bare and sorted(float(t) for t in re.findall(r"(?<![\w.])\d+\.\d+", bare)) == [0.07, 0.29]
+    assert set(bench.BOUND) == {2, 3, 4, 5} and all(isinstance(v, str) for v in bench.BOUND.values())
+    assert bench.backend_name("nccl").startswith("RCCL") and bench.backend_name("gloo").startswith("gloo")
