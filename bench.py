@@ -303,9 +303,9 @@ def limiter_sentence(config, rf):
     head = {
         2: "priced against HBM as the north star asks (%.2f of its peak, fp32 %.2f of the vector peak); what limits it is VALU issue and the "
            "LDS exchanges running in series at 3 waves per SIMD",
-        3: "90 % window overlap: every sample is transformed ten times, one workgroup of 135 KB of LDS per CU at 2 waves per SIMD; HBM sees "
+        3: "90 %% window overlap: every sample is transformed ten times, one workgroup of 135 KB of LDS per CU at 2 waves per SIMD; HBM sees "
            "%.2f of its peak, fp32 %.2f of the vector peak",
-        4: "90 % window overlap at N = 64: 16 transforms per wave, issue-latency bound; HBM sees %.2f of its peak, fp32 %.2f of the vector peak",
+        4: "90 %% window overlap at N = 64: 16 transforms per wave, issue-latency bound; HBM sees %.2f of its peak, fp32 %.2f of the vector peak",
         5: "two streaming passes over the first-stage scratch Z: HBM sees %.2f of its peak in algorithmic bytes, fp32 %.2f of the vector peak",
     }[config] % (rf["frac"], rf["flop_frac"])
     return head + "; " + pipes
