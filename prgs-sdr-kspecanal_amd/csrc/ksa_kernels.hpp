@@ -434,9 +434,12 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
 #endif
 #ifndef KSA_PF
-#define KSA_PF 1   // reuse path: the RM new samples of window k+1 are requested while window k is transformed (round 4: fits without
-                   // spilling since the transposed exchange layout; +1.9 % at config 2, +0.6 % at 75 % overlap, +1..3 % at N = 2048;
-                   // N = 1024 would spill 6-8 registers and large batches run the pair kernel there anyway)
+#define KSA_PF 1   // reuse path: the RM new samples of window k+1 are requested while window k is transformed.  Fits since the
+                   // transposed exchange layout of round 4: alone 155 VGPRs and no spill; together with the middle twiddles in
+                   // VGPRs (TWM_REGS) the N = 4096 reuse kernels sit at the 168-VGPR cap with TWO registers spilled (12 bytes of
+                   // scratch per lane), stored before the window loop and reloaded in the output stage -- never inside the loop
+                   // (tests/test_isa_regression.py holds the compiler to that).  +1.9 % at config 2, +0.6 % at 75 % overlap,
+                   // +1..3 % at N = 2048; N = 1024 would spill 6-8 registers and large batches run the pair kernel there anyway
 #endif
   // (requesting the first window of the workgroup's NEXT frame before this frame's output stage, with LDS-only barriers
   //  around the staging stores so that the loads stay in flight, measured 2.5 % SLOWER at config 2: profiles/r04_ab_prefetch_twiddles.txt)
