@@ -218,7 +218,6 @@ def spawn_ranks(n):
     sys.stdout.flush()
 
 
-OVERLAP_DEFAULT = 0             # decided by the A/B of profiles/r05_ab_accum_overlap.txt
 SECONDARY_BUDGET_S = 150.0      # all side runs together; the driver's limit for the whole bench is 600 s
 
 
@@ -374,9 +373,6 @@ def parse_args():
                     help="headline run on one GPU: skip the short runs of the other BASELINE configurations (3, 4, 5)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1, zeroSpan only: run the multi-GPU merge path on a one-rank group, to price its fixed cost")
-    ap.add_argument("--overlap", type=int, choices=(0, 1), default=OVERLAP_DEFAULT,
-                    help="zeroSpan, one GPU: 1 = overlap mode (ksa_set_overlap): the accumulate + commit of step i runs on the engine's "
-                         "side stream under the spectrum stage of step i+1, the per-frame dB rows alternate between two buffers")
     ap.add_argument("--inprocess", action="store_true",
                     help="ONE process, --gpus engines placed on the visible devices (engine r on device r %% device_count), merged by "
                          "ksa_allreduce_state / ksa_scan_allstitch: the torch-free multi-GPU form (no RCCL)")
@@ -427,6 +423,7 @@ def roofline_block(cfg, args, eng, units_per_step, kern_ms, launches, step_s):
             "valu_issue_frac": rec.get("valu_issue_frac"), "shader_clock_ghz": rec.get("shader_clock_ghz"),
             # live: median over XCDs and launches of d(s_memtime) / d(s_memrealtime) x 100 MHz around each timed spectrum stage
             "shader_clock_ghz_live": clock_live, "shader_clock_samples": clock_samples,
+            "shader_clock_ghz_live_range": getattr(eng, "prof_clock_range", None),
             # the fp32 fraction of what the chip can issue at the clock it actually held (the peak is quoted at 2.4 GHz)
             "flop_frac_at_clock": (tflops / (FP32_PEAK_TFLOPS * clock / NOMINAL_CLOCK_GHZ)) if clock else None,
             "flop_frac_at_clock_source": ("shader_clock_ghz_live" if clock_live else "shader_clock_ghz (stored counter pass)") if clock else None,
@@ -480,27 +477,16 @@ def main():
     resident_iq = lambda units: make_resident_iq(torch, orc, args, cfg, units, rank)
 
     strong_step = None
-    overlap = False
     if cfg["mode"] == "zerospan":
         frames = args.frames or cfg["frames"]
         units_per_step = frames                       # per rank
         iq = resident_iq(frames)
         eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=cfg["window"], gain=GAIN, xres=cfg["xres"],
                                  max_frames=frames, device=local, stream=stream)
-        # overlap mode needs commit-at-once batches (one GPU, no collective); the dB rows of consecutive steps then go to
-        # two alternating buffers, so that step i+1 does not overwrite what step i's accumulate still reads
-        overlap = bool(args.overlap) and world == 1 and not args.force_collective
-        cur_dbs = [torch.empty((frames, n), dtype=torch.float32, device="cuda") for _ in range(2 if overlap else 1)]
-        cur_db = cur_dbs[0]
+        cur_db = torch.empty((frames, n), dtype=torch.float32, device="cuda")
         hm_rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
         run = ksa_dist.ShardedZeroSpan(eng, rank, world, always_collective=args.force_collective)
-        if overlap:
-            eng.set_overlap(True)
-        flip = [0]
-
-        def step():
-            flip[0] ^= 1
-            run.step(iq, fmt, frames, cur_db=cur_dbs[flip[0] % len(cur_dbs)], hm_rows=hm_rows)
+        step = lambda: run.step(iq, fmt, frames, cur_db=cur_db, hm_rows=hm_rows)
         if world > 1 and frames // world >= 1:
             fs = frames // world                      # the SAME job as one GPU's step, split over the ranks
             strong_step = (fs, lambda: run.step(iq, fmt, fs, cur_db=cur_db, hm_rows=hm_rows))
@@ -595,7 +581,6 @@ def main():
             "config": dict({"workload": cfg["workload"], "baseline_config": args.config,
                             "input": "complex64" if args.fmt == "c64" else "uint8", "samples_per_unit": full,
                             "windows_per_unit": nwin, "sharding": sharding, "collective": collective,
-                            "accumulate_overlap": bool(cfg["mode"] == "zerospan" and overlap),
                             "collective_bytes_per_rank_per_step": coll_bytes}, **batch),
             "roofline": roofline_block(cfg, args, eng, units_per_step, kern_ms, launches, step_s),
         }

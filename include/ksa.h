@@ -26,7 +26,7 @@ extern "C" {
 
 #define KSA_ABI_VERSION 4 /* 2: ksa_set_adj takes its target; allreduce_state, host-pointer scan pass, sharded scan entries
                              3: ksa_scan_spectra_dev, ksa_read_hm_rows, ksa_read_view; entry points restore the caller's current device
-                             4: ksa_set_overlap, ksa_prof_clock
+                             4: ksa_prof_clock
                              A binding takes the number from ksa_abi_version() of the library it loaded, never from a literal. */
 #define KSA_HM_ROWS 128 /* waterfall history depth: maxHM K:448, fftHMMax K:611 */
 
@@ -75,20 +75,9 @@ void ksa_destroy(ksa_engine* e);
  * enqueued on the old one is ordered in front of whatever is enqueued on the new one (event wait): a stream handed in
  * here must therefore stay alive until the engine's next ksa_set_stream (or ksa_destroy). */
 int ksa_set_stream(ksa_engine* e, void* hip_stream);
-/* Waits for everything the engine has enqueued (its stream and, in overlap mode, its side stream) on the ENGINE's device,
- * whatever device is current in the caller. */
+/* Waits for everything the engine has enqueued on its stream, on the ENGINE's device, whatever device is current in the
+ * caller. */
 int ksa_synchronize(ksa_engine* e);
-/* Overlap mode (off by default; no reference counterpart -- the reference's loop K:460-484 is strictly sequential).  on != 0:
- * a committed ksa_frames_dev batch that fills the GPU several times over runs its Max/Min/Avg accumulate + commit
- * (K:470-476) on an engine-owned side stream behind its spectrum stage, so the spectrum stage of the NEXT ksa_frames_dev
- * batch -- bound by VALU / LDS, not by HBM -- starts at once and the accumulate's re-read of the dB rows runs under it.
- * Results are bit-identical to the sequential order (the side stream is serial and every other entry point that touches
- * the state, the partial block or the internal spectra joins it first).  Contract while it is on: the cur_db_dev rows of a
- * batch must stay allocated and unwritten until the engine's next joining call (any entry point other than a further
- * overlapping ksa_frames_dev, or ksa_synchronize); a batch that would write into rows a pending accumulate still reads
- * waits for it (correct, but nothing overlaps: alternate two cur_db_dev buffers; with cur_db_dev == NULL the engine
- * alternates two internal blocks itself). */
-int ksa_set_overlap(ksa_engine* e, int32_t on);
 
 /* ---- sdr_curscan drop-ins (K:351-397) ------------------------------------------------------- */
 /* One captured block in, linear fftshifted magnitudes out (host memory both sides). */
@@ -256,10 +245,11 @@ int ksa_prof_enable(ksa_engine* e, int32_t on);
 int ksa_prof_read(ksa_engine* e, double* spectrum_ms, int64_t* launches);
 /* Shader clock the chip held under the profiled spectrum stages since the last ksa_prof_enable(1): a stamp kernel on
  * the engine's stream directly before and directly after each profiled stage (outside the event pair of ksa_prof_read)
- * reads s_memtime (shader cycles) and s_memrealtime (100 MHz) on every XCD; *shader_ghz is the median of d(cycles) /
- * d(time) over the XCDs and the last <= 64 stages, *samples the (XCD, stage) pairs behind it.  The spectrum kernels
- * themselves carry no stamp; an unprofiled run launches nothing extra. */
-int ksa_prof_clock(ksa_engine* e, double* shader_ghz, int64_t* samples);
+ * reads s_memtime (shader cycles) and s_memrealtime (100 MHz) on most CUs; *shader_ghz is the median of d(cycles) /
+ * d(time) over the CUs stamped at both ends and the last <= 16 stages, *ghz_min / *ghz_max (optional) the extremes,
+ * *samples the (CU, stage) pairs behind them.  The spectrum kernels themselves carry no stamp; an unprofiled run launches
+ * nothing extra. */
+int ksa_prof_clock(ksa_engine* e, double* shader_ghz, double* ghz_min, double* ghz_max, int64_t* samples);
 /* Resources of the spectrum kernel chosen for this engine (for DESIGN.md / bench.py). */
 int ksa_kernel_info(ksa_engine* e, int32_t* threads, int32_t* lds_bytes, int32_t* vgprs,
                     int32_t* grid, int32_t* path /* 0 = single-workgroup LDS FFT, 16 points per thread; 3 = the same with

@@ -43,7 +43,6 @@ SIGNATURES = {
     "ksa_destroy": (None, [_P]),
     "ksa_set_stream": (C.c_int, [_P, _P]),
     "ksa_synchronize": (C.c_int, [_P]),
-    "ksa_set_overlap": (C.c_int, [_P, _I32]),
     "ksa_curscan_c64": (C.c_int, [_P, _P, _P]),
     "ksa_curscan_u8": (C.c_int, [_P, _P, _P]),
     "ksa_curscan_dev": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P]),
@@ -86,7 +85,7 @@ SIGNATURES = {
     "ksa_host_free": (C.c_int, [_P]),
     "ksa_prof_enable": (C.c_int, [_P, _I32]),
     "ksa_prof_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
-    "ksa_prof_clock": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    "ksa_prof_clock": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I64)]),
     "ksa_kernel_info": (C.c_int, [_P] + [C.POINTER(_I32)] * 5),
 }
 

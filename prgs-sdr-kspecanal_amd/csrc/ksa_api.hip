@@ -123,16 +123,6 @@ struct ksa_engine {
   float* d_scan_send = nullptr;   // [nhalo][npasses][N] own bands packed for the right neighbours
   size_t scan_halo_cap = 0, scan_send_cap = 0;   // floats
   hipEvent_t ev_ready = nullptr, ev_copied = nullptr, ev_stream = nullptr;
-  // accumulate / reduce / commit of a committed batch on an engine-owned side stream, under the spectrum stage of the NEXT
-  // batch (ksa_set_overlap; off by default).  side_pending: work queued there that the main stream has not joined yet;
-  // [side_db_lo, side_db_hi) = the dB rows it still reads (a later batch that would overwrite them joins first).
-  hipStream_t side = nullptr;
-  hipEvent_t ev_spec = nullptr, ev_side = nullptr;
-  bool overlap = false, side_pending = false;
-  const float* side_db_lo = nullptr;
-  const float* side_db_hi = nullptr;
-  float* d_frames_b = nullptr;  // second internal [max_frames][N] block: batches without a caller buffer alternate (overlap mode)
-  int frames_flip = 0;
   // N > 16384: radix-16 / 32 / 64 decimation in frequency in front of the single-workgroup kernel (ksa_dif16.hpp)
   int sub_n = 0;                // size of the single-workgroup transform: fft_size (path 0) or fft_size/16 (path 2)
   float2* d_dif_tw = nullptr;   // [6][N1]
@@ -165,7 +155,7 @@ struct ksa_engine {
   double prof_ms = 0;
   long long prof_launches = 0;
   // clock stamps around profiled spectrum stages (ksa_prof_clock, ksa::clock_stamp_kernel)
-  unsigned long long* d_clk = nullptr;      // [CLK_SLOTS][before | after][xcd][memtime, memrealtime]
+  unsigned long long* d_clk = nullptr;      // [CLK_SLOTS][before | after][CLK_KEYS][memtime, memrealtime]
   long long clk_launches = 0;
 };
 
@@ -368,16 +358,6 @@ int launch_spec_n(ksa_engine* e, const SpecParams& p, bool cfg_only) {
   }
 }
 
-// The main stream waits for whatever the side stream still has queued (overlap mode): called before anything on the main
-// stream reads or writes what the accumulate / reduce / commit kernels touch (d_part, d_partial, the state, the dB rows).
-int join_side(ksa_engine* e) {
-  if (!e->side_pending) return 0;
-  HIP_OK(hipStreamWaitEvent(e->stream, e->ev_side, 0));
-  e->side_pending = false;
-  e->side_db_lo = e->side_db_hi = nullptr;
-  return 0;
-}
-
 int prof_begin(ksa_engine* e, hipEvent_t* a, hipEvent_t* b) {
   *a = *b = nullptr;
   if (!e->prof || e->prof_events.size() >= 8192) return 0;
@@ -514,7 +494,7 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
   p.dbg = dbg;
 #endif
   // profiled stage: clock stamps directly before and after it on the same stream (ksa_prof_clock), OUTSIDE the event pair
-  unsigned long long* const clk = (e->prof && e->d_clk) ? e->d_clk + (size_t)(e->clk_launches++ % ksa::CLK_SLOTS) * 2 * ksa::CLK_XCDS * 2 : nullptr;
+  ksa::u64x2* const clk = (e->prof && e->d_clk) ? reinterpret_cast<ksa::u64x2*>(e->d_clk) + (size_t)(e->clk_launches++ % ksa::CLK_SLOTS) * 2 * ksa::CLK_KEYS : nullptr;
   if (clk) hipLaunchKernelGGL(ksa::clock_stamp_kernel, dim3(ksa::CLK_WGS), dim3(64), 0, e->stream, clk, 0);
   hipEvent_t ea, eb;
   if (prof_begin(e, &ea, &eb)) return 1;
@@ -550,7 +530,7 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
   return 0;
 }
 
-int run_accumulate(ksa_engine* e, const float* db, int nframes, long long first_index, long long total, hipStream_t st) {
+int run_accumulate(ksa_engine* e, const float* db, int nframes, long long first_index, long long total) {
   const int n = e->cfg.fft_size;
   ksa::AccParams a{};
   a.db = db;
@@ -565,18 +545,18 @@ int run_accumulate(ksa_engine* e, const float* db, int nframes, long long first_
   a.part = e->d_part;
   const int tb = 256, gx = (n + tb - 1) / tb;
   const int tb4 = 64, gx4 = (n / 4 + tb4 - 1) / tb4;     // 4 bins per thread
-  hipLaunchKernelGGL(ksa::accumulate_partial_kernel, dim3(gx4, chunks), dim3(tb4), 0, st, a);
+  hipLaunchKernelGGL(ksa::accumulate_partial_kernel, dim3(gx4, chunks), dim3(tb4), 0, e->stream, a);
   const int owns_last = first_index + nframes == total;
-  hipLaunchKernelGGL(ksa::accumulate_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, e->d_part, chunks, n,
+  hipLaunchKernelGGL(ksa::accumulate_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, e->stream, e->d_part, chunks, n,
                      db + (long long)(nframes - 1) * n, owns_last, e->d_partial);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
-int do_commit(ksa_engine* e, long long total, int local_frames, hipStream_t st) {
+int do_commit(ksa_engine* e, long long total, int local_frames) {
   const int n = e->cfg.fft_size;
   const int tb = 256, gx = (n + tb - 1) / tb;
-  hipLaunchKernelGGL(ksa::commit_kernel, dim3(gx), dim3(tb), 0, st, e->d_partial, e->d_state, n,
+  hipLaunchKernelGGL(ksa::commit_kernel, dim3(gx), dim3(tb), 0, e->stream, e->d_partial, e->d_state, n,
                      e->has_max, e->has_min, e->has_avg, total, e->b_max, e->b_min, e->b_avg);
   HIP_OK(hipGetLastError());
   e->has_max |= e->b_max;
@@ -851,9 +831,8 @@ void ksa_destroy(ksa_engine* e) {
   hipSetDevice(e->cfg.device);
   hipDeviceSynchronize();
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-  for (hipEvent_t ev : {e->ev_ready, e->ev_copied, e->ev_stream, e->ev_spec, e->ev_side}) if (ev) hipEventDestroy(ev);
-  if (e->side) hipStreamDestroy(e->side);
-  void* ptrs[] = {e->d_frames_b, e->d_clk, e->d_gather, e->d_scan_stage, e->d_scan_rows, e->d_scan_halo, e->d_scan_send,
+  for (hipEvent_t ev : {e->ev_ready, e->ev_copied, e->ev_stream}) if (ev) hipEventDestroy(ev);
+  void* ptrs[] = {e->d_clk, e->d_gather, e->d_scan_stage, e->d_scan_rows, e->d_scan_halo, e->d_scan_send,
                   e->d_starts, e->d_start_last, e->d_window, e->d_window32, e->d_tw_mid, e->d_tw_last, e->d_adj, e->d_scan_adj,
                   e->d_iq_stage, e->d_frames, e->d_part, e->d_xchg, e->d_state, e->d_scan_state, e->d_scan_hm,
                   e->d_levels, e->d_parts, e->d_highs, e->d_scan_avg_rows, e->d_dif_tw, e->d_dif_z, e->d_dif_y, e->d_ones, e->d_starts_b};
@@ -870,7 +849,6 @@ int ksa_set_stream(ksa_engine* e, void* hip_stream) {
   //  ksa_destroy of this engine)
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;        // (side-stream work is ordered in front of the new stream through the old one)
   if (!e->ev_stream) HIP_OK(hipEventCreateWithFlags(&e->ev_stream, hipEventDisableTiming));
   HIP_OK(hipEventRecord(e->ev_stream, e->stream));
   HIP_OK(hipStreamWaitEvent(ns, e->ev_stream, 0));
@@ -883,22 +861,7 @@ int ksa_synchronize(ksa_engine* e) {
   // (the default engine stream is the NULL stream, which means "the null stream of the CURRENT device": select the engine's)
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   HIP_OK(hipStreamSynchronize(e->stream));
-  return 0;
-}
-
-int ksa_set_overlap(ksa_engine* e, int32_t on) {
-  if (!e) return fail("null engine");
-  DeviceGuard dev_guard;
-  HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
-  if (on && !e->side) {
-    HIP_OK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&e->ev_spec, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
-  }
-  e->overlap = on != 0;
   return 0;
 }
 
@@ -908,7 +871,6 @@ int ksa_curscan_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t fram
   if (out_mode < KSA_OUT_LINEAR || out_mode > KSA_OUT_DB_CLIP) return fail("unknown out_mode %d", out_mode);
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   return run_spectrum(e, iq_dev, fmt, frame_stride, nframes, out_mode, out_dev, false, nullptr);
 }
 
@@ -916,7 +878,6 @@ static int curscan_host(ksa_engine* e, const void* iq_host, int fmt, float* mag_
   if (!e || !iq_host || !mag_host) return fail("null argument");
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   HIP_OK(hipMemcpyAsync(e->d_iq_stage, iq_host, (size_t)e->cfg.full_size * sample_bytes(fmt), hipMemcpyHostToDevice, e->stream));
   if (run_spectrum(e, e->d_iq_stage, fmt, 0, 1, KSA_OUT_LINEAR, e->d_frames, false, nullptr)) return 1;
   HIP_OK(hipMemcpyAsync(mag_host, e->d_frames, (size_t)e->cfg.fft_size * 4, hipMemcpyDeviceToHost, e->stream));
@@ -933,36 +894,11 @@ int ksa_frames_dev(ksa_engine* e, const void* iq_dev, int32_t fmt, int64_t frame
   if (first_index < 0 || first_index + nframes > total_frames) return fail("batch [%lld,+%d) outside run of %lld frames", (long long)first_index, nframes, (long long)total_frames);
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  const size_t row = (size_t)e->cfg.fft_size;
-  // Overlap mode (ksa_set_overlap), committed batches that fill the GPU several times over: accumulate / reduce / commit
-  // run on the engine's side stream behind this batch's spectrum stage, so that the NEXT batch's spectrum stage (VALU /
-  // LDS bound, no use for the HBM bandwidth the accumulate's re-read of the dB rows wants) starts at once.
-  const bool side = e->overlap && commit && nframes >= 4 * e->num_cu * e->blocks_per_cu;
-  float* db = cur_db_dev;
-  if (!db) {
-    db = e->d_frames;
-    if (side) {            // alternate two internal blocks, or the next batch would have to wait for this one's accumulate
-      if (!e->d_frames_b) HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_frames_b), (size_t)e->cfg.max_frames * row * 4));
-      db = (e->frames_flip ^= 1) ? e->d_frames_b : e->d_frames;
-    }
-  }
-  // the pending accumulate still reads its batch's dB rows: a batch that writes into them waits for it (no overlap, no race)
-  if (e->side_pending && (!side || (db < e->side_db_hi && db + (size_t)nframes * row > e->side_db_lo)) && join_side(e)) return 1;
+  float* db = cur_db_dev ? cur_db_dev : e->d_frames;
   if (run_spectrum(e, iq_dev, fmt, frame_stride, nframes, KSA_OUT_DB, db, e->cfg.hm_width > 0, hm_rows_dev)) return 1;
-  if (side) {
-    HIP_OK(hipEventRecord(e->ev_spec, e->stream));
-    HIP_OK(hipStreamWaitEvent(e->side, e->ev_spec, 0));
-    if (run_accumulate(e, db, nframes, first_index, total_frames, e->side)) return 1;
-    if (do_commit(e, total_frames, nframes, e->side)) return 1;
-    HIP_OK(hipEventRecord(e->ev_side, e->side));
-    e->side_pending = true;
-    e->side_db_lo = db;
-    e->side_db_hi = db + (size_t)nframes * row;
-    return 0;
-  }
-  if (run_accumulate(e, db, nframes, first_index, total_frames, e->stream)) return 1;
+  if (run_accumulate(e, db, nframes, first_index, total_frames)) return 1;
   e->pending_frames = nframes;
-  if (commit) return do_commit(e, total_frames, nframes, e->stream);
+  if (commit) return do_commit(e, total_frames, nframes);
   return 0;
 }
 
@@ -983,7 +919,6 @@ int ksa_frame_spectrum(ksa_engine* e, const float* mag_host) {
   if (!e || !mag_host) return fail("null argument");
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   const int n = e->cfg.fft_size;
   float* lin = reinterpret_cast<float*>(e->d_iq_stage);  // full_size*8 bytes >= N*4
   HIP_OK(hipMemcpyAsync(lin, mag_host, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
@@ -1001,26 +936,20 @@ int ksa_frame_spectrum(ksa_engine* e, const float* mag_host) {
   p.hm_first = 0;
   hipLaunchKernelGGL(ksa::db_rows_kernel, dim3(std::max(1, std::min(64, n / 256)), 1), dim3(256), 0, e->stream, p);
   HIP_OK(hipGetLastError());
-  if (run_accumulate(e, e->d_frames, 1, 0, 1, e->stream)) return 1;
-  if (do_commit(e, 1, 1, e->stream)) return 1;
+  if (run_accumulate(e, e->d_frames, 1, 0, 1)) return 1;
+  if (do_commit(e, 1, 1)) return 1;
   HIP_OK(hipStreamSynchronize(e->stream));
   return 0;
 }
 
 int ksa_partial_dev(ksa_engine* e, float** partial_dev) {
   if (!e || !partial_dev) return fail("null argument");
-  DeviceGuard dev_guard;
-  HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   *partial_dev = e->d_partial;
   return 0;
 }
 
 int ksa_exchange_dev(ksa_engine* e, float** xchg_dev, int64_t* nfloats) {
   if (!e || !xchg_dev || !nfloats) return fail("null argument");
-  DeviceGuard dev_guard;
-  HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   *xchg_dev = e->d_xchg;
   *nfloats = 4ll * e->cfg.fft_size + (long long)KSA_HM_ROWS * e->cfg.hm_width;
   return 0;
@@ -1036,7 +965,6 @@ int ksa_merge_gathered_dev(ksa_engine* e, const float* gathered_dev, int32_t wor
   if (hm_index0 < 0 || hm_index0 >= KSA_HM_ROWS) return fail("hm_index0 %d outside 0..127", hm_index0);
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   const int n = e->cfg.fft_size, w = e->cfg.hm_width;
   const long long stride = 4ll * n + (long long)KSA_HM_ROWS * w;
   const long long total = (long long)world * frames_per_rank;
@@ -1044,7 +972,7 @@ int ksa_merge_gathered_dev(ksa_engine* e, const float* gathered_dev, int32_t wor
   hipLaunchKernelGGL(ksa::merge_gathered_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, e->stream,
                      gathered_dev, world, stride, n, e->d_partial, e->d_hm, w, hm_index0, frames_per_rank, total);
   HIP_OK(hipGetLastError());
-  if (do_commit(e, total, 0, e->stream)) return 1;
+  if (do_commit(e, total, 0)) return 1;
   e->hm_index = (int)((hm_index0 + total) % KSA_HM_ROWS);
   return 0;
 }
@@ -1054,8 +982,7 @@ int ksa_commit(ksa_engine* e, int64_t total_frames) {
   if (e->pending_frames <= 0) return fail("ksa_commit without a pending ksa_frames_dev(commit=0)");
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
-  return do_commit(e, total_frames, e->pending_frames, e->stream);
+  return do_commit(e, total_frames, e->pending_frames);
 }
 
 int ksa_set_flags(ksa_engine* e, int32_t b_max, int32_t b_min, int32_t b_avg) {
@@ -1071,7 +998,6 @@ int ksa_set_adj(ksa_engine* e, int32_t scan, const float* adj_host, int32_t n) {
   if (scan && !e->cfg.scan_total_entries) return fail("engine was created without scan geometry");
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   HIP_OK(hipStreamSynchronize(e->stream));
   float** slot = scan ? &e->d_scan_adj : &e->d_adj;
   if (*slot) hipFree(*slot);
@@ -1086,7 +1012,6 @@ int ksa_reset_state(ksa_engine* e) {
   if (!e) return fail("null engine");
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   HIP_OK(hipMemsetAsync(e->d_state, 0, (size_t)4 * e->cfg.fft_size * 4, e->stream));
   if (e->d_hm) HIP_OK(hipMemsetAsync(e->d_hm, 0, (size_t)KSA_HM_ROWS * e->cfg.hm_width * 4, e->stream));  // np.zeros K:456
   e->frames_seen = 0;
@@ -1101,7 +1026,6 @@ int ksa_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg
   if (!e) return fail("null engine");
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   if (hm && !e->d_hm) return fail("engine has no waterfall (hm_width 0)");      // (validated before the first copy is enqueued)
   const size_t nb = (size_t)e->cfg.fft_size * 4;
   float* dst[4] = {cur, max, min, avg};
@@ -1118,9 +1042,6 @@ int ksa_read_state(ksa_engine* e, float* cur, float* max, float* min, float* avg
 
 int ksa_state_dev(ksa_engine* e, float** state_dev, float** hm_ring_dev) {
   if (!e) return fail("null engine");
-  DeviceGuard dev_guard;
-  HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;       // (the caller reads the state on the engine's stream)
   if (state_dev) *state_dev = e->d_state;
   if (hm_ring_dev) *hm_ring_dev = e->d_hm;
   return 0;
@@ -1490,7 +1411,6 @@ int ksa_scan_stitch_passes_dev(ksa_engine* e, const float* step_db_dev, int32_t 
 // step_ok entry is 0 is replaced by the dummy band: ones(fftSize) through the same two steps (K:637-641)
 static int scan_spectra(ksa_engine* e, const void* iq_dev, int fmt, long long frame_stride, int frames, const uint8_t* step_ok,
                         float* out_dev) {
-  if (join_side(e)) return 1;        // (ksa_scan_passes_dev writes the internal block a pending zeroSpan accumulate may read)
   if (run_spectrum(e, iq_dev, fmt, frame_stride, frames, KSA_OUT_DB_CLIP, out_dev, false, nullptr)) return 1;
   if (step_ok) {
     const float v = (float)(10.0 * std::log10(std::max(1.0, (double)e->cfg.min_amp)) - (double)e->cfg.gain);
@@ -1569,7 +1489,6 @@ static int levels_to_scratch(ksa_engine* e, int scan, int mode, int cells) {
   if (scan && !n) return fail("engine was created without scan geometry");
   if (cells < 1 || n % cells) return fail("cells %d must divide %d", cells, n);
   HIP_OK(hipSetDevice(e->cfg.device));     // (the exported caller holds the DeviceGuard)
-  if (join_side(e)) return 1;
   if (!e->d_levels || e->levels_cap < cells) {
     if (e->d_levels) hipFree(e->d_levels);
     e->d_levels = nullptr;
@@ -1705,7 +1624,7 @@ int ksa_prof_enable(ksa_engine* e, int32_t on) {
   e->prof_events.clear();
   e->prof = on != 0;
   if (on) {
-    const size_t bytes = (size_t)ksa::CLK_SLOTS * 2 * ksa::CLK_XCDS * 2 * sizeof(unsigned long long);
+    const size_t bytes = (size_t)ksa::CLK_SLOTS * 2 * ksa::CLK_KEYS * 2 * sizeof(unsigned long long);
     if (!e->d_clk) HIP_OK(hipMalloc(reinterpret_cast<void**>(&e->d_clk), bytes));
     HIP_OK(hipMemsetAsync(e->d_clk, 0, bytes, e->stream));
     e->clk_launches = 0;
@@ -1717,7 +1636,6 @@ int ksa_prof_read(ksa_engine* e, double* spectrum_ms, int64_t* launches) {
   if (!e) return fail("null engine");
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
-  if (join_side(e)) return 1;
   HIP_OK(hipStreamSynchronize(e->stream));
   double ms = 0;
   for (auto& pr : e->prof_events) {
@@ -1730,30 +1648,34 @@ int ksa_prof_read(ksa_engine* e, double* spectrum_ms, int64_t* launches) {
   return 0;
 }
 
-int ksa_prof_clock(ksa_engine* e, double* shader_ghz, int64_t* samples) {
+int ksa_prof_clock(ksa_engine* e, double* shader_ghz, double* ghz_min, double* ghz_max, int64_t* samples) {
   if (!e || !shader_ghz) return fail("null argument");
   *shader_ghz = 0.0;
+  if (ghz_min) *ghz_min = 0.0;
+  if (ghz_max) *ghz_max = 0.0;
   if (samples) *samples = 0;
   if (!e->d_clk) return fail("ksa_prof_clock: profiling was never enabled on this engine");
   DeviceGuard dev_guard;
   HIP_OK(hipSetDevice(e->cfg.device));
   HIP_OK(hipStreamSynchronize(e->stream));
-  const size_t per = (size_t)2 * ksa::CLK_XCDS * 2;
+  const size_t per = (size_t)2 * ksa::CLK_KEYS * 2;      // qwords per profiled launch
   std::vector<unsigned long long> h((size_t)ksa::CLK_SLOTS * per);
   HIP_OK(hipMemcpy(h.data(), e->d_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   std::vector<double> ghz;
   for (int slot = 0; slot < ksa::CLK_SLOTS; ++slot)
-    for (int x = 0; x < ksa::CLK_XCDS; ++x) {
-      const unsigned long long* b0 = &h[slot * per + (size_t)x * 2];
-      const unsigned long long* b1 = b0 + (size_t)ksa::CLK_XCDS * 2;
+    for (int key = 0; key < ksa::CLK_KEYS; ++key) {
+      const unsigned long long* b0 = &h[slot * per + (size_t)key * 2];
+      const unsigned long long* b1 = b0 + (size_t)ksa::CLK_KEYS * 2;
       const unsigned long long c0 = b0[0], r0 = b0[1], c1 = b1[0], r1 = b1[1];
-      if (r0 && r1 > r0 && c1 > c0 && r1 - r0 >= 1000)          // stamped on this XCD at both ends, >= 10 us apart (100 MHz ticks)
+      if (r0 && r1 > r0 && c1 > c0 && r1 - r0 >= 1000)    // this CU was stamped at both ends, >= 10 us apart (100 MHz ticks)
         ghz.push_back((double)(c1 - c0) / (double)(r1 - r0) * 0.1);
     }
   if (samples) *samples = (int64_t)ghz.size();
   if (ghz.empty()) return 0;
-  std::nth_element(ghz.begin(), ghz.begin() + ghz.size() / 2, ghz.end());
+  std::sort(ghz.begin(), ghz.end());
   *shader_ghz = ghz[ghz.size() / 2];
+  if (ghz_min) *ghz_min = ghz.front();
+  if (ghz_max) *ghz_max = ghz.back();
   return 0;
 }
 

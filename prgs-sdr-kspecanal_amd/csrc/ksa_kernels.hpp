@@ -49,24 +49,29 @@ struct SpecParams {
 
 // Shader clock held under the spectrum stage (bench.py `shader_clock_ghz_live`, ksa_prof_clock): a stamp kernel of CLK_WGS
 // single-wave workgroups runs on the engine's stream directly before and directly after a PROFILED spectrum stage; each wave
-// reads s_memtime (shader cycles of its XCD) and s_memrealtime (the constant 100 MHz counter) and stores them under its XCD's
-// id.  The host takes d(memtime) / d(memrealtime) x 100 MHz per XCD and the median over the XCDs and launches
-// (MI355X_MICROARCH.md, 'DVFS give-back' item 6).  The spectrum kernels themselves carry NO stamp: their register files are
-// full, and two stamps inside spectrum_kernel<4096,c64,8,AVG> cost three more spilled VGPRs (2 -> 5; measured, removed).
-// The interval includes the two launch gaps (a few us next to the 5 ms of a config-2 launch).
-constexpr int CLK_WGS = 64;       // enough single-wave workgroups to land on every XCD
-constexpr int CLK_XCDS = 8;
-constexpr int CLK_SLOTS = 64;     // profiled launches whose stamps are kept (ring)
-// out = [which = 0 before | 1 after][xcd][2] = {memtime, memrealtime}; several waves of one XCD write the same slot, any of
-// them is as good as the other (they run within a microsecond of each other)
-__global__ __launch_bounds__(64) void clock_stamp_kernel(unsigned long long* out, int which) {
+// reads s_memtime (shader cycles) and s_memrealtime (the constant 100 MHz counter) and stores the pair under the identity of
+// the hardware it ran on (XCC_ID and the SE / SH / CU fields of HW_ID), so that the host only ever subtracts two readings of
+// the SAME counter: d(memtime) / d(memrealtime) x 100 MHz per (XCD, SE, CU) seen at both ends, median over those and over the
+// launches (MI355X_MICROARCH.md, 'DVFS give-back' item 6).  (Keyed by XCC_ID alone the quotients scattered from 0.1 to 1000
+// GHz on short stages: s_memtime readings taken on different shader engines are not comparable.)  The spectrum kernels
+// themselves carry NO stamp: their register files are full, and two stamps inside spectrum_kernel<4096,c64,8,AVG> cost
+// three more spilled VGPRs (2 -> 5; measured, removed).  The interval includes the two launch gaps (a few us).
+constexpr int CLK_WGS = 2048;     // single-wave workgroups per stamp launch: several per CU, so that most CUs are hit at both ends
+constexpr int CLK_KEYS = 4096;    // XCC_ID[3:0] << 8 | HW_ID[15:8] (CU_ID[3:0], SH_ID, SE_ID[2:0])
+constexpr int CLK_SLOTS = 16;     // profiled launches whose stamps are kept (ring)
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+// out = [which = 0 before | 1 after][key] = {memtime, memrealtime}, one 16-byte store; waves that share a key overwrite each
+// other (any of them is as good as the other: they run within a microsecond)
+__global__ __launch_bounds__(64) void clock_stamp_kernel(u64x2* out, int which) {
   unsigned long long c, r;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r)::"memory");
-  const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & (CLK_XCDS - 1);   // HW_REG_XCC_ID[3:0]
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));   // hwreg(HW_REG_XCC_ID, 0, 4)
+  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | ((8 - 1) << 11));     // hwreg(HW_REG_HW_ID, 8, 8): CU, SH, SE
   if (threadIdx.x == 0) {
-    unsigned long long* o = out + ((long long)which * CLK_XCDS + xcc) * 2;
-    o[0] = c;
-    o[1] = r;
+    u64x2 v;
+    v.x = c;
+    v.y = r;
+    out[(size_t)which * CLK_KEYS + (((xcc & 15u) << 8) | (hw & 255u))] = v;
   }
 }
 
@@ -444,6 +449,9 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   // (requesting the first window of the workgroup's NEXT frame before this frame's output stage, with LDS-only barriers
   //  around the staging stores so that the loads stay in flight, measured 2.5 % SLOWER at config 2: profiles/r04_ab_prefetch_twiddles.txt)
   constexpr bool PF = KSA_PF && RM > 0 && N >= 2048;
+  // (General path, RM == 0: letting the raw-sample registers take the NEXT round's 16 loads as soon as a round has converted
+  //  them was measured at N = 64, round 5: 168 instead of 121 VGPRs = three instead of four waves per SIMD, config 4 14.9 vs
+  //  17.7 G FFT/s (-16 %; uint8 -15 %), profiles/r05_ab_pf0.txt.  Removed.)
   for (int vf = blockIdx.x; vf < p.nframes * NP; vf += gridDim.x) {
     const int frame = vf / NP, part = vf - frame * NP;
     // this workgroup's contiguous share of the frame's windows (contiguous keeps the sample reuse valid)

@@ -147,12 +147,6 @@ class SpectrumEngine:
     def synchronize(self):
         check(lib.ksa_synchronize(self._h))
 
-    def set_overlap(self, on=True):
-        """Overlap mode (ksa_set_overlap): the accumulate + commit of a large committed batch runs on the engine's side
-        stream under the NEXT batch's spectrum stage.  While on, a batch's cur_db rows must stay untouched until the
-        engine's next joining call (anything but a further frames_dev) or synchronize(); alternate two cur_db buffers."""
-        check(lib.ksa_set_overlap(self._h, int(bool(on))))
-
     @property
     def num_windows(self):
         return len(self.starts)
@@ -410,8 +404,9 @@ class SpectrumEngine:
     def prof_clock(self):
         """(shader clock in GHz held under the profiled spectrum launches, workgroup samples behind it); (None, 0) when the
         kernel in use carries no stamps."""
-        ghz, n = C.c_double(), C.c_int64()
-        check(lib.ksa_prof_clock(self._h, C.byref(ghz), C.byref(n)))
+        ghz, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        check(lib.ksa_prof_clock(self._h, C.byref(ghz), C.byref(lo), C.byref(hi), C.byref(n)))
+        self.prof_clock_range = (lo.value, hi.value) if n.value else None
         return (ghz.value if n.value else None), n.value
 
 

@@ -1,6 +1,5 @@
 """GPU tests, round 5: the documented reference-side binding (INTEGRATION.md sections 2 and 3) executed verbatim against the
-reference-run goldens, overlap mode (the accumulate of batch i on the engine's side stream under the spectrum stage of
-batch i+1) bit for bit against the sequential order, the live shader-clock figure, and the bench record's own
+reference-run goldens, the live shader-clock figure, and the bench record's own
 consistency (the limiter sentence quotes the fields beside it; the uint8 side run; the backend the collective names).
 All through the C ABI; tolerances as test_gpu_parity.py."""
 import ctypes as C
@@ -98,109 +97,8 @@ def test_integration_section3_runs_verbatim_against_the_zerospan_golden(ksa, tor
     ns["ksa"].ksa_destroy(d["ksa"])
 
 
-# ------------------------------------------------------------------------------- overlap mode (ksa_set_overlap)
 def _engine(ksa, n, full, q, frames, **kw):
     return ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning", gain=GAIN, xres=512, max_frames=frames, **kw)
-
-
-@pytest.mark.parametrize("n,full,q,frames,buffers", [(4096, 32768, 0.5, 3200, 2), (4096, 32768, 0.5, 3200, 1), (4096, 32768, 0.5, 3200, 0),
-                                                     (1024, 8192, 0.25, 12800, 2), (65536, 131072, 0.25, 4, 2)])
-def test_overlap_mode_is_bit_identical_to_the_sequential_order(ksa, torch_cuda, n, full, q, frames, buffers):
-    """VERDICT r04 item 5.  With ksa_set_overlap(1) a committed batch's accumulate / reduce / commit (K:470-476) run on the
-    engine's side stream under the NEXT batch's spectrum stage.  Five batches through an overlapping engine -- with two
-    alternating cur_db buffers, with ONE buffer (every batch then waits for the pending accumulate: the hazard path) and with
-    none (the engine alternates two internal blocks) -- must leave exactly the bits a sequential engine leaves: state, ring,
-    and the per-frame rows of the last two batches.  The 65536-point case has batches below the overlap threshold (overlap
-    on, side stream never used) and the 1024-point case runs the pair kernel."""
-    torch = torch_cuda
-    distinct = min(frames, 64)
-    x = orc.synth_iq(full * distinct, 555 + n).astype(np.complex64).reshape(distinct, full)
-    tile = torch.view_as_real(torch.from_numpy(x)).to("cuda")
-    iq = tile.repeat((frames + distinct - 1) // distinct, 1, 1)[:frames].contiguous()
-    steps = 5
-    seq = _engine(ksa, n, full, q, frames)
-    ovl = _engine(ksa, n, full, q, frames)
-    ovl.set_overlap(True)
-    rows_seq = [torch.empty((frames, n), dtype=torch.float32, device="cuda") for _ in range(2)]
-    rows_ovl = [torch.empty((frames, n), dtype=torch.float32, device="cuda") for _ in range(max(buffers, 1))]
-    for i in range(steps):
-        # a different slice of the input every step (rolled), so that no two batches give the same state
-        batch = torch.roll(iq, shifts=i * 7, dims=0) if i else iq
-        seq.frames_dev(batch, ksa.FMT_C64, frames, cur_db=rows_seq[i % 2])
-        seq.synchronize()
-        ovl.frames_dev(batch, ksa.FMT_C64, frames, cur_db=rows_ovl[i % len(rows_ovl)] if buffers else None)
-        if i == 2:
-            # a state read in the middle of the run joins the side stream and sees batch 2 committed
-            a, b = seq.state(), ovl.state()
-            for k in CURVES + ("fftHM",):
-                assert np.array_equal(a[k], b[k], equal_nan=True), "mid-run %s" % k
-    ovl.synchronize()
-    a, b = seq.state(), ovl.state()
-    assert a["frames"] == b["frames"] == steps * frames and a["hm_index"] == b["hm_index"]
-    for k in CURVES + ("fftHM",):
-        assert np.array_equal(a[k], b[k], equal_nan=True), k
-    if buffers == 2:
-        torch.cuda.synchronize()
-        for i in (steps - 2, steps - 1):
-            assert torch.equal(rows_seq[i % 2], rows_ovl[i % 2])
-    # switching it off again joins and keeps working
-    ovl.set_overlap(False)
-    seq.frames_dev(iq, ksa.FMT_C64, frames)
-    ovl.frames_dev(iq, ksa.FMT_C64, frames)
-    a, b = seq.state(), ovl.state()
-    for k in CURVES:
-        assert np.array_equal(a[k], b[k], equal_nan=True), "after switching off: " + k
-    seq.close()
-    ovl.close()
-
-
-def test_overlap_mode_joins_before_every_other_use_of_the_state(ksa, torch_cuda):
-    """Entry points that touch what the side stream works on (the uncommitted-batch path, levels / markers, reset, the
-    exchange block of the multi-GPU merge, a stream switch) join it first: after an overlapping batch each of them sees that
-    batch committed, exactly as on a sequential engine."""
-    torch = torch_cuda
-    n, full, q, frames = 2048, 16384, 0.5, 6400
-    x = orc.synth_iq(full * 32, 91).astype(np.complex64).reshape(32, full)
-    iq = torch.view_as_real(torch.from_numpy(x)).to("cuda").repeat(frames // 32, 1, 1).contiguous()
-    seq, ovl = _engine(ksa, n, full, q, frames), _engine(ksa, n, full, q, frames)
-    ovl.set_overlap(True)
-    for e in (seq, ovl):
-        e.frames_dev(iq, ksa.FMT_C64, frames)
-    assert np.array_equal(seq.levels(256, "MAX"), ovl.levels(256, "MAX"), equal_nan=True)
-    for e in (seq, ovl):
-        e.frames_dev(iq, ksa.FMT_C64, frames)
-    ia, la = seq.highs(256, "AVG", "max", 4.0, 5)
-    ib, lb = ovl.highs(256, "AVG", "max", 4.0, 5)
-    assert np.array_equal(ia, ib) and np.array_equal(la, lb)
-    # an uncommitted batch right behind an overlapping one (the multi-GPU path): partial block + commit
-    for e in (seq, ovl):
-        e.frames_dev(iq, ksa.FMT_C64, frames)
-        e.frames_dev(iq, ksa.FMT_C64, 640, first_index=0, total_frames=640, commit=False)
-    pa = torch.as_tensor(seq.partial(), device="cuda").clone()
-    pb = torch.as_tensor(ovl.partial(), device="cuda").clone()
-    torch.cuda.synchronize()
-    assert torch.equal(pa, pb)
-    for e in (seq, ovl):
-        e.commit(640)
-    s2 = torch.cuda.Stream()
-    for e in (seq, ovl):
-        e.frames_dev(iq, ksa.FMT_C64, frames)
-        e.set_stream(s2.cuda_stream)
-        e.frames_dev(iq, ksa.FMT_C64, frames)
-    a, b = seq.state(), ovl.state()
-    for k in CURVES + ("fftHM",):
-        assert np.array_equal(a[k], b[k], equal_nan=True), k
-    for e in (seq, ovl):
-        e.frames_dev(iq, ksa.FMT_C64, frames)
-        e.reset()
-        e.frames_dev(iq, ksa.FMT_C64, frames)
-    a, b = seq.state(), ovl.state()
-    assert a["frames"] == b["frames"] == frames
-    for k in CURVES:
-        assert np.array_equal(a[k], b[k], equal_nan=True), "after reset: " + k
-    for e in (seq, ovl):
-        e.set_stream(None)
-        e.close()
 
 
 # ------------------------------------------------------------------------------- live shader clock (ksa_prof_clock)
@@ -222,7 +120,7 @@ def test_prof_clock_reports_the_clock_held_under_the_stage(ksa, torch_cuda):
     ms, launches = prof.prof_read()
     ghz, samples = prof.prof_clock()
     assert launches == 4 and ms > 0
-    assert samples >= 4 and 1.0 < ghz < 2.6, (ghz, samples)
+    assert samples >= 4 and 1.0 < ghz < 3.0, (ghz, samples, prof.prof_clock_range)
     a, b = plain.state(), prof.state()
     for k in CURVES + ("fftHM",):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
@@ -238,7 +136,7 @@ def _decimals(text):
 @pytest.mark.parametrize("cfg,extra", [(2, ["--frames", "8192"]), (3, ["--passes", "8"]), (4, ["--passes", "16"]), (5, ["--frames", "16"])])
 def test_bench_limiter_quotes_the_fields_beside_it(cfg, extra):
     """every decimal number in roofline.limiter is one of the block's own fields (two decimals), the live
-    clock and flop_frac_at_clock are present and consistent, and the record names overlap mode."""
+    clock and flop_frac_at_clock are present and consistent."""
     d = _bench(["--config", str(cfg), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-secondary"] + extra)
     rf = d["roofline"]
     fields = [rf[k] for k in ("frac", "flop_frac", "valu_issue_frac", "lds_frac", "traffic_over_algorithmic") if rf.get(k) is not None]
@@ -251,16 +149,6 @@ def test_bench_limiter_quotes_the_fields_beside_it(cfg, extra):
     assert rf["shader_clock_ghz_live"] and 1.0 < rf["shader_clock_ghz_live"] < 2.6 and rf["shader_clock_samples"] >= 3
     want = rf["tflops"] / (157.3 * rf["shader_clock_ghz_live"] / 2.4)
     assert abs(rf["flop_frac_at_clock"] - want) < 1e-9 and rf["flop_frac_at_clock_source"] == "shader_clock_ghz_live"
-    assert d["config"]["accumulate_overlap"] in (True, False)
-
-
-def test_bench_overlap_flag_changes_the_schedule_not_the_result():
-    """`--overlap 1` and `--overlap 0` run the same work (same value formula, same launches) and say which one they ran."""
-    a = _bench(["--frames", "8192", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-secondary", "--overlap", "0"])
-    b = _bench(["--frames", "8192", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-secondary", "--overlap", "1"])
-    assert a["config"]["accumulate_overlap"] is False and b["config"]["accumulate_overlap"] is True
-    for d in (a, b):
-        assert abs(d["value"] * d["ms_per_step"] / 1e3 - 8192 * 15) / (8192 * 15) < 1e-6 and d["roofline"]["launches"] == 4
 
 
 def test_bench_rehearsal_lines_say_so_and_name_their_backend():
