@@ -127,12 +127,35 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
   for (int q = tid; q < N / 4; q += T) {
     float4 r = red4[q];
     if constexpr (S > 1) {
+      // slot combine, in slot order (the order fixes the rounding of the AVG sum).  The loads of KSA_SLOT_CH slots are issued
+      // before the first is used: as a rolled loop of dependent load -> combine steps this was 15 LDS round trips per frame at
+      // N = 64 -- with the stores and the dB math 15.6 % of a wave's time at config 4 (profiles/r05_c4_stamps.txt).  Measured
+      // (profiles/r05_ab_slot.txt): config 4 +3.5 %, N = 64 / 32 at 50 % overlap +24 % / +23 %; 5 slots in flight keep N = 64 at
+      // 121 VGPRs (four waves per SIMD; 15 in flight: 153).  A variant with one bin per lane (all 64 lanes busy instead of N/4)
+      // on top measured +0.4 % at config 4 and -3 % at N = 64 / 50 %: not kept.
+#ifndef KSA_SLOT_CH
+#define KSA_SLOT_CH 5
+#endif
+      constexpr int CH = (S - 1) < KSA_SLOT_CH ? (S - 1) : KSA_SLOT_CH;
 #pragma unroll 1
-      for (int s2 = 1; s2 < S; ++s2) {
-        const float4 x = red4[s2 * (RS / 4) + q];
-        if (p.cumu == CUMU_AVG) { r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w; }
-        else if (p.cumu == CUMU_MAX) { r.x = nan_max(r.x, x.x); r.y = nan_max(r.y, x.y); r.z = nan_max(r.z, x.z); r.w = nan_max(r.w, x.w); }
-        else { r.x = nan_min(r.x, x.x); r.y = nan_min(r.y, x.y); r.z = nan_min(r.z, x.z); r.w = nan_min(r.w, x.w); }
+      for (int s0 = 1; s0 < S; s0 += CH) {
+        float4 x[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (s0 + u < S) x[u] = red4[(s0 + u) * (RS / 4) + q];
+        if (p.cumu == CUMU_AVG) {
+#pragma unroll
+          for (int u = 0; u < CH; ++u)
+            if (s0 + u < S) { r.x += x[u].x; r.y += x[u].y; r.z += x[u].z; r.w += x[u].w; }
+        } else if (p.cumu == CUMU_MAX) {
+#pragma unroll
+          for (int u = 0; u < CH; ++u)
+            if (s0 + u < S) { r.x = nan_max(r.x, x[u].x); r.y = nan_max(r.y, x[u].y); r.z = nan_max(r.z, x[u].z); r.w = nan_max(r.w, x[u].w); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < CH; ++u)
+            if (s0 + u < S) { r.x = nan_min(r.x, x[u].x); r.y = nan_min(r.y, x[u].y); r.z = nan_min(r.z, x[u].z); r.w = nan_min(r.w, x[u].w); }
+        }
       }
     }
     float o[4] = {r.x, r.y, r.z, r.w};
@@ -451,7 +474,8 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   constexpr bool PF = KSA_PF && RM > 0 && N >= 2048;
   // (General path, RM == 0: letting the raw-sample registers take the NEXT round's 16 loads as soon as a round has converted
   //  them was measured at N = 64, round 5: 168 instead of 121 VGPRs = three instead of four waves per SIMD, config 4 14.9 vs
-  //  17.7 G FFT/s (-16 %; uint8 -15 %), profiles/r05_ab_pf0.txt.  Removed.)
+  //  17.7 G FFT/s (-16 %; uint8 -15 %); held to 128 VGPRs the same code spills 98-110 registers, with the 6-twiddle last pass
+  //  as well: profiles/r05_ab_pf0.txt.  Removed.)
   for (int vf = blockIdx.x; vf < p.nframes * NP; vf += gridDim.x) {
     const int frame = vf / NP, part = vf - frame * NP;
     // this workgroup's contiguous share of the frame's windows (contiguous keeps the sample reuse valid)
