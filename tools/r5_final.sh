@@ -25,21 +25,13 @@ for f in ('bench_c$k.json','bench_c${k}_u8.json'):
     d=json.load(open('$O/'+f)); r=d['roofline']
     print('c$k %-16s %.3f MFFT/s %.1f GS/s ms/step %.3f kern %.3f ms frac %.4f step %.4f flop %.3f traffic %s cpu %s' % (f, d['value']/1e6, d['msamples_per_s']/1e3, d['ms_per_step'], r['avg_kernel_ms'], r['frac'], r['frac_step'], r['flop_frac'], r['traffic'], d.get('cpu_baseline',{}).get('value')))"
   done
-  # multi-rank rehearsals on this one GPU over gloo, and the in-process leg (functional records, not scaling measurements)
-  for spec in "2 2" "2 4" "3 2" "4 3" "5 2"; do
-    set -- $spec
-    KSA_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --config $1 --gpus $2 --steps 3 --warmup 1 --no-cpu $( [ $1 = 2 ] && echo "--frames 4096" ) $( [ $1 = 3 ] && echo "--passes 32" ) $( [ $1 = 4 ] && echo "--passes 64" ) $( [ $1 = 5 ] && echo "--frames 128" ) > $O/gloo_c$1_g$2.json 2> $O/gloo_c$1_g$2.err || echo "gloo c$1 g$2 failed"
-  done
-  for spec in "2 8 --frames 8192" "4 8 --passes 128" "3 8 --passes 32"; do
-    set -- $spec
-    timeout -k 10 400 python3 bench.py --inprocess --config $1 --gpus $2 $3 $4 --steps 5 --warmup 1 --no-cpu > $O/inproc_c$1_g$2.json 2> $O/inproc_c$1_g$2.err || echo "inprocess c$1 failed"
-  done
+  # (multi-rank rehearsals over gloo and the in-process leg: tools/node_day.sh rehearsal)
   timeout -k 10 300 python3 tools/latency_host.py > $O/latency_host.txt 2>&1 || echo "latency_host failed"
 fi
 if [ $what = prof ] || [ $what = all ]; then
   for k in 2 3 4 5; do tools/profile_bench.sh r05_c$k --config $k > $O/prof_c$k.log 2>&1; done
 fi
-if [ $what = wide ] || [ $what = all ]; then
+if [ $what = wide ]; then
   # the radix-32 / 64 first stages (N = 524288 / 1048576): spectrum-stage time and the kernel trace behind it
   cd /tmp && export TMPDIR=/tmp
   for n in 524288 1048576; do
