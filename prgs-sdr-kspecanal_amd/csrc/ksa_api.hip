@@ -487,8 +487,8 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
   p.hm_index0 = e->hm_index;
   p.hm_first = std::max(0, nframes - KSA_HM_ROWS);
 #ifdef KSA_STAMPS
-  static unsigned long long* dbg = nullptr;   // diagnostic build: 4096 blocks x 16 waves x 10 segments
-  const size_t dbg_n = 4096 * 16 * 10;
+  static unsigned long long* dbg = nullptr;   // diagnostic build: 4096 blocks x 16 waves x 12 segments
+  const size_t dbg_n = 4096 * 16 * 12;
   if (!dbg) hipMalloc(reinterpret_cast<void**>(&dbg), dbg_n * 8);
   hipMemsetAsync(dbg, 0, dbg_n * 8, e->stream);
   p.dbg = dbg;
@@ -510,16 +510,16 @@ int run_spectrum(ksa_engine* e, const void* iq, int fmt, long long stride, int n
     hipStreamSynchronize(e->stream);
     std::vector<unsigned long long> h(dbg_n);
     hipMemcpy(h.data(), dbg, dbg_n * 8, hipMemcpyDeviceToHost);
-    double sum[10] = {0};
+    double sum[12] = {0};
     long long waves = 0;
-    for (size_t w = 0; w < dbg_n / 10; ++w) {
-      if (!h[w * 10 + 0] && !h[w * 10 + 7]) continue;
+    for (size_t w = 0; w < dbg_n / 12; ++w) {
+      if (!h[w * 12 + 0] && !h[w * 12 + 7]) continue;
       ++waves;
-      for (int i = 0; i < 10; ++i) sum[i] += (double)h[w * 10 + i];
+      for (int i = 0; i < 12; ++i) sum[i] += (double)h[w * 12 + i];
     }
     if (FILE* f = fopen(path, "a")) {
       fprintf(f, "waves %lld nframes %d nwin %d :", waves, nframes, p.nwin);
-      for (int i = 0; i < 10; ++i) fprintf(f, " %.0f", waves ? sum[i] / waves : 0.0);
+      for (int i = 0; i < 12; ++i) fprintf(f, " %.0f", waves ? sum[i] / waves : 0.0);
       fprintf(f, "\n");
       fclose(f);
     }

@@ -113,7 +113,56 @@ __device__ __forceinline__ float out_db(float lin, int out_mode, float gain, flo
 template <int N, int S>
 struct RedStride { static constexpr int value = (KSA_RED_SKEW && (N == 32 || N == 64)) ? N + 4 : N; };
 
-template <int N, int T, int S>
+// lane ^ 1 / lane ^ 2 inside a DPP quad (quad_transpose4 below)
+__device__ __forceinline__ float dpp_quad_xor1(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ float dpp_quad_xor2(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
+}
+// The common shapes of the output stage (one transform per workgroup, AVG fold, dB output, no waterfall cell or one that a
+// shuffle tree inside a wave reduces: 4 <= g <= 256) as a loop whose body has NO run-time mode branch: the generic loop
+// below decides fold mode, output unit and cell path per element with ~25 scalar branches per step, and the cycle stamps put
+// 8.3 % of a config-2 wave's time into it (profiles/r05_c2_stamps.txt).  Same arithmetic in the same order: identical rows.
+#ifndef KSA_FINISH_FAST
+#define KSA_FINISH_FAST 1
+#endif
+template <int N, int T, int OM, bool HM>
+__device__ __forceinline__ void finish_rows_avg(const SpecParams& p, const float* red, float* orow, float* hm_row, float* hm_ring,
+                                                int g, int tid) {
+  const float4* red4 = reinterpret_cast<const float4*>(red);
+  const int lanes = g >> 2;                   // lanes per waterfall cell (HM only): 1 .. 64
+  const int cell_shift = 31 - __builtin_clz(g | 1);
+  // (issuing the next step's LDS read before this step's values are used, and lane ^ 1 / lane ^ 2 as DPP quad permutes instead of
+  //  ds_bpermute, were both measured on top: +-0 and -0.9 % at config 2, profiles/r05_ab_finish.txt -- the plain loop stays)
+#pragma unroll 1
+  for (int q = tid; q < N / 4; q += T) {
+    const float4 r = red4[q];
+    float o[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = out_db(o[u] * p.scale, OM, p.gain, p.min_amp);
+    const int sh = (4 * q + N / 2) & (N - 1);
+    *reinterpret_cast<float4*>(orow + sh) = make_float4(o[0], o[1], o[2], o[3]);
+    if constexpr (HM) {
+      if (p.adj) {
+        const float4 a = *reinterpret_cast<const float4*>(p.adj + sh);
+        o[0] -= a.x; o[1] -= a.y; o[2] -= a.z; o[3] -= a.w;
+      }
+      float hv = fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
+      const bool bad = __builtin_isunordered(o[0], o[1]) | __builtin_isunordered(o[2], o[3]);
+      for (int m = 1; m < lanes; m <<= 1) hv = fmaxf(hv, __shfl_xor(hv, m));
+      const unsigned long long nb = __ballot(bad);
+      if ((tid & (lanes - 1)) == 0) {
+        const unsigned long long cell = lanes >= 64 ? ~0ull : (((1ull << lanes) - 1ull) << (tid & 63));
+        if (nb & cell) hv = __builtin_nanf("");
+        if (hm_row) hm_row[sh >> cell_shift] = hv;
+        if (hm_ring) hm_ring[sh >> cell_shift] = hv;
+      }
+    }
+  }
+}
+
+template <int N, int T, int S, int CM = 0>   // CM: the kernel's compile-time fold mode (0 = decided at run time)
 __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, int frame, int tid) {
   constexpr int RS = RedStride<N, S>::value;
   const int g = p.hm_w > 0 ? N / p.hm_w : 0;  // bins per waterfall cell
@@ -122,6 +171,18 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
   float* const hm_row = p.hm_rows ? p.hm_rows + (long long)frame * p.hm_w : nullptr;
   float* const hm_ring = (p.hm_ring && frame >= p.hm_first)
                              ? p.hm_ring + ((p.hm_index0 + frame) % HM_ROWS) * p.hm_w : nullptr;
+  if constexpr (KSA_FINISH_FAST && S == 1 && N >= 1024 && (CM == 0 || CM == CUMU_AVG)) {
+    if (p.cumu == CUMU_AVG && p.out_mode != OUT_LINEAR && (g == 0 || (hm_fast && g >= 4))) {
+      if (p.out_mode == OUT_DB) {
+        if (g == 0) finish_rows_avg<N, T, OUT_DB, false>(p, red, orow, hm_row, hm_ring, g, tid);
+        else finish_rows_avg<N, T, OUT_DB, true>(p, red, orow, hm_row, hm_ring, g, tid);
+      } else {
+        if (g == 0) finish_rows_avg<N, T, OUT_DB_CLIP, false>(p, red, orow, hm_row, hm_ring, g, tid);
+        else finish_rows_avg<N, T, OUT_DB_CLIP, true>(p, red, orow, hm_row, hm_ring, g, tid);
+      }
+      return;
+    }
+  }
   const float4* red4 = reinterpret_cast<const float4*>(red);
 #pragma unroll 1
   for (int q = tid; q < N / 4; q += T) {
@@ -335,12 +396,6 @@ struct Tune {
 // 4x4 transpose of r[0..3] across the four lanes of a DPP quad: afterwards r[j] of lane q holds what r[q] of lane j
 // held.  Two butterfly stages (lane ^ 1 on register pairs (0,1), (2,3); lane ^ 2 on (0,2), (1,3)); per pair one select
 // of the element to hand over, one quad_perm move and two selects: the wave-local form of a Stockham exchange.
-__device__ __forceinline__ float dpp_quad_xor1(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
-}
-__device__ __forceinline__ float dpp_quad_xor2(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
-}
 __device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2, float& r3, bool odd1, bool odd2) {
   {
     const float g = dpp_quad_xor1(odd1 ? r0 : r1);
@@ -457,7 +512,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   };
 
 #ifdef KSA_STAMPS
-  unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
 #endif
@@ -653,14 +708,16 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
     // does not share registers with the transform loop.
     float* const red = reinterpret_cast<float*>(lds);  // [S][N] floats, inside the data region
     __syncthreads();
+    KSA_STAMP(9);    // output stage, part 1: the barrier behind the last window (slowest wave, outstanding loads)
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[slot * RedStride<N, S>::value + l + L * perm<16>(i)] = acc[i];
     __syncthreads();
+    KSA_STAMP(10);   // part 2: fold -> LDS staging + barrier
 #ifdef KSA_ABL_NOFIN   // timing-only ablation build: one store per thread keeps the fold alive
     if (red[tid] == 123.456f) p.out[tid] = red[tid];
 #else
     if (NP == 1) {
-      finish_frame<N, T, S>(p, red, frame, tid);
+      finish_frame<N, T, S, CM>(p, red, frame, tid);
     } else {
       // partial fold of this share, slots combined, natural bin order; combine_parts_kernel finishes the frame
       float4* const dst = reinterpret_cast<float4*>(p.part_out + (long long)vf * N);
@@ -683,7 +740,7 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   }
 #ifdef KSA_STAMPS
   if (p.dbg && (tid & 63) == 0) {
-    for (int i = 0; i < 10; ++i) p.dbg[((long long)blockIdx.x * (T / 64) + tid / 64) * 10 + i] = seg[i];
+    for (int i = 0; i < 12; ++i) p.dbg[((long long)blockIdx.x * (T / 64) + tid / 64) * 12 + i] = seg[i];
   }
 #endif
 }

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
   } while (0)
 
 #ifdef KSA_STAMPS   // diagnostic build: where a wave's time goes (segments named at the KSA_STAMP calls below)
-  unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
 #endif
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
     for (int i = 0; i < 32; ++i) red[l + L * ((i >> 4) + 2 * perm<16>(i & 15))] = acc[i];
     __syncthreads();
     if (NP == 1) {
-      finish_frame<N, T, 1>(p, red, frame, l);
+      finish_frame<N, T, 1, CM>(p, red, frame, l);
     } else {
       float4* const dst = reinterpret_cast<float4*>(p.part_out + (long long)vf * N);
       const float4* red4 = reinterpret_cast<const float4*>(red);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(Plan32<N>::T, Plan32<N>::WPS) void spectrum32_kerne
   }
 #ifdef KSA_STAMPS
   if (p.dbg && (l & 63) == 0) {
-    for (int i = 0; i < 10; ++i) p.dbg[((long long)blockIdx.x * (T / 64) + l / 64) * 10 + i] = seg[i];
+    for (int i = 0; i < 12; ++i) p.dbg[((long long)blockIdx.x * (T / 64) + l / 64) * 12 + i] = seg[i];
   }
 #endif
 }

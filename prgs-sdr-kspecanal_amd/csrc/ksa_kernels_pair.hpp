@@ -209,8 +209,8 @@ __global__ __launch_bounds__(Plan<N>::T, 2) void spectrum_pair_kernel(const Spec
       red[2 * N + l + L * perm<16>(i)] = acc[i].y;
     }
     __syncthreads();
-    finish_frame<N, T, 1>(p, red, fa, l);
-    if (has_b) finish_frame<N, T, 1>(p, red + 2 * N, fb, l);
+    finish_frame<N, T, 1, CM>(p, red, fa, l);
+    if (has_b) finish_frame<N, T, 1, CM>(p, red + 2 * N, fb, l);
     // (the next pair's first exchange barrier orders these LDS reads before its writes)
   }
 }

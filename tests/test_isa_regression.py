@@ -82,12 +82,15 @@ def product_asm(tmp_path_factory):
 
 
 def test_config2_kernel_keeps_its_single_exchange_reads_and_its_spills_outside_the_window_loop(product_asm):
-    """spectrum_kernel<4096, c64, RM = 8, AVG>: 168 VGPRs = three waves per SIMD, at most 2 spilled registers (12 bytes of
-    scratch per lane) stored before / reloaded after the window loop, and inside the loop exactly the 32 single ds_read_b64
-    of the two exchanges, their 32 ds_write_b64-equivalents, four barriers and no scratch instruction."""
+    """spectrum_kernel<4096, c64, RM = 8, AVG>: 168 VGPRs = three waves per SIMD, at most 8 spilled registers (36 bytes of
+    scratch per lane; 2 / 12 bytes before the branch-free output-stage loop of round 5, which the MAX / MIN variants do not
+    carry) stored before / reloaded after the window loop, and inside the loop exactly the 32 single ds_read_b64 of the two
+    exchanges, four barriers, the 8 sample loads of a window and no scratch instruction (rounds 4 and 5)."""
     body, tail = _find(product_asm, "spectrum_kernel<4096, 0, 8, 1>")
     assert _resource(tail, "NumVgprs") <= 168 and _resource(tail, "Occupancy") == 3
-    assert _resource(tail, "ScratchSize") <= 12, "more spilled registers than the documented two"
+    assert _resource(tail, "ScratchSize") <= 36, "more spilled registers than the documented eight"
+    _, tail_max = _find(product_asm, "spectrum_kernel<4096, 0, 8, 2>")
+    assert _resource(tail_max, "ScratchSize") <= 12, "the MAX-fold variant spills more than its documented two registers"
     loop = _mix(_window_loop(body, 16))
     assert loop["ds_read_b64"] == 32, dict(loop)
     assert loop["ds_read2_b64"] + loop["ds_read2st64_b64"] == 0, "hipcc merged exchange reads into ds_read2_b64 again"
@@ -95,7 +98,9 @@ def test_config2_kernel_keeps_its_single_exchange_reads_and_its_spills_outside_t
     assert loop["s_barrier"] == 4
     assert loop["buffer_load_dwordx2"] == 8, "the window loop loads its 8 new samples per thread (RM = 8), nothing else"
     whole = _mix(body)
-    assert sum(v for k, v in whole.items() if k.startswith("scratch_")) <= 2     # one store, one reload
+    # spill stores in front of the frame loop's body, reloads in the (several) copies of the output stage: per frame, not per window
+    assert sum(v for k, v in whole.items() if k.startswith("scratch_store")) <= 6
+    assert sum(v for k, v in whole.items() if k.startswith("scratch_load")) <= 24
     # the uint8 variant of the same kernel (row A0) spills nothing
     body8, tail8 = _find(product_asm, "spectrum_kernel<4096, 1, 8, 1>")
     assert _resource(tail8, "ScratchSize") == 0 and _resource(tail8, "Occupancy") == 3
