@@ -127,9 +127,10 @@ __device__ __forceinline__ float dpp_quad_xor2(float x) {
 #ifndef KSA_FINISH_FAST
 #define KSA_FINISH_FAST 1
 #endif
-template <int N, int T, int OM, bool HM>
+template <int N, int T, int S, int OM, int HM>   // HM: 0 no waterfall cell, 1 one bin per cell (g == 1), 2 shuffle tree (4 <= g <= 256)
 __device__ __forceinline__ void finish_rows_avg(const SpecParams& p, const float* red, float* orow, float* hm_row, float* hm_ring,
                                                 int g, int tid) {
+  constexpr int RS = RedStride<N, S>::value;
   const float4* red4 = reinterpret_cast<const float4*>(red);
   const int lanes = g >> 2;                   // lanes per waterfall cell (HM only): 1 .. 64
   const int cell_shift = 31 - __builtin_clz(g | 1);
@@ -137,17 +138,36 @@ __device__ __forceinline__ void finish_rows_avg(const SpecParams& p, const float
   //  ds_bpermute, were both measured on top: +-0 and -0.9 % at config 2, profiles/r05_ab_finish.txt -- the plain loop stays)
 #pragma unroll 1
   for (int q = tid; q < N / 4; q += T) {
-    const float4 r = red4[q];
+    float4 r = red4[q];
+    if constexpr (S > 1) {       // slot combine in slot order, five slots' loads in flight (see finish_frame)
+      constexpr int CH = (S - 1) < 5 ? (S - 1) : 5;
+#pragma unroll 1
+      for (int s0 = 1; s0 < S; s0 += CH) {
+        float4 x[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (s0 + u < S) x[u] = red4[(s0 + u) * (RS / 4) + q];
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (s0 + u < S) { r.x += x[u].x; r.y += x[u].y; r.z += x[u].z; r.w += x[u].w; }
+      }
+    }
     float o[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) o[u] = out_db(o[u] * p.scale, OM, p.gain, p.min_amp);
+    for (int u = 0; u < 4; ++u) o[u] = OM != OUT_LINEAR ? out_db(o[u] * p.scale, OM, p.gain, p.min_amp) : o[u] * p.scale;
     const int sh = (4 * q + N / 2) & (N - 1);
     *reinterpret_cast<float4*>(orow + sh) = make_float4(o[0], o[1], o[2], o[3]);
-    if constexpr (HM) {
+    if constexpr (HM != 0) {
       if (p.adj) {
         const float4 a = *reinterpret_cast<const float4*>(p.adj + sh);
         o[0] -= a.x; o[1] -= a.y; o[2] -= a.z; o[3] -= a.w;
       }
+    }
+    if constexpr (HM == 1) {
+      if (hm_row) *reinterpret_cast<float4*>(hm_row + sh) = make_float4(o[0], o[1], o[2], o[3]);
+      if (hm_ring) *reinterpret_cast<float4*>(hm_ring + sh) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if constexpr (HM == 2) {
       float hv = fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
       const bool bad = __builtin_isunordered(o[0], o[1]) | __builtin_isunordered(o[2], o[3]);
       for (int m = 1; m < lanes; m <<= 1) hv = fmaxf(hv, __shfl_xor(hv, m));
@@ -171,14 +191,23 @@ __device__ __forceinline__ void finish_frame(const SpecParams& p, float* red, in
   float* const hm_row = p.hm_rows ? p.hm_rows + (long long)frame * p.hm_w : nullptr;
   float* const hm_ring = (p.hm_ring && frame >= p.hm_first)
                              ? p.hm_ring + ((p.hm_index0 + frame) % HM_ROWS) * p.hm_w : nullptr;
-  if constexpr (KSA_FINISH_FAST && S == 1 && N >= 1024 && (CM == 0 || CM == CUMU_AVG)) {
-    if (p.cumu == CUMU_AVG && p.out_mode != OUT_LINEAR && (g == 0 || (hm_fast && g >= 4))) {
+#ifndef KSA_FINISH_FAST_SMALL
+#define KSA_FINISH_FAST_SMALL 1   // the same for the small transforms (S > 1 slots per workgroup)
+#endif
+  if constexpr (KSA_FINISH_FAST && (S == 1 ? N >= 1024 : KSA_FINISH_FAST_SMALL) && (CM == 0 || CM == CUMU_AVG)) {
+    if (p.cumu == CUMU_AVG && p.out_mode == OUT_LINEAR && g == 0) {      // sdr_curscan's linear spectra; the second stage of N >= 32768
+      finish_rows_avg<N, T, S, OUT_LINEAR, 0>(p, red, orow, hm_row, hm_ring, g, tid);
+      return;
+    }
+    if (p.cumu == CUMU_AVG && p.out_mode != OUT_LINEAR && (g <= 1 || (hm_fast && g >= 4))) {
       if (p.out_mode == OUT_DB) {
-        if (g == 0) finish_rows_avg<N, T, OUT_DB, false>(p, red, orow, hm_row, hm_ring, g, tid);
-        else finish_rows_avg<N, T, OUT_DB, true>(p, red, orow, hm_row, hm_ring, g, tid);
-      } else {
-        if (g == 0) finish_rows_avg<N, T, OUT_DB_CLIP, false>(p, red, orow, hm_row, hm_ring, g, tid);
-        else finish_rows_avg<N, T, OUT_DB_CLIP, true>(p, red, orow, hm_row, hm_ring, g, tid);
+        if (g == 0) finish_rows_avg<N, T, S, OUT_DB, 0>(p, red, orow, hm_row, hm_ring, g, tid);
+        else if (g == 1) finish_rows_avg<N, T, S, OUT_DB, 1>(p, red, orow, hm_row, hm_ring, g, tid);
+        else finish_rows_avg<N, T, S, OUT_DB, 2>(p, red, orow, hm_row, hm_ring, g, tid);
+      } else {      // (the scan's clipped output never rides with a waterfall cell: its rows come from Fft.Avg per pass, K:696-697)
+        if (g == 0) finish_rows_avg<N, T, S, OUT_DB_CLIP, 0>(p, red, orow, hm_row, hm_ring, g, tid);
+        else if (g == 1) finish_rows_avg<N, T, S, OUT_DB_CLIP, 1>(p, red, orow, hm_row, hm_ring, g, tid);
+        else finish_rows_avg<N, T, S, OUT_DB_CLIP, 2>(p, red, orow, hm_row, hm_ring, g, tid);
       }
       return;
     }
