@@ -98,9 +98,10 @@ def test_config2_kernel_keeps_its_single_exchange_reads_and_its_spills_outside_t
     assert loop["s_barrier"] == 4
     assert loop["buffer_load_dwordx2"] == 8, "the window loop loads its 8 new samples per thread (RM = 8), nothing else"
     whole = _mix(body)
-    # spill stores in front of the frame loop's body, reloads in the (several) copies of the output stage: per frame, not per window
+    # spill stores in front of the frame loop's body, reloads in the copies of the output stage (one per output unit / cell
+    # path: a static count, each frame runs ONE of them): per frame, never per window
     assert sum(v for k, v in whole.items() if k.startswith("scratch_store")) <= 6
-    assert sum(v for k, v in whole.items() if k.startswith("scratch_load")) <= 24
+    assert sum(v for k, v in whole.items() if k.startswith("scratch_load")) <= 40
     # the uint8 variant of the same kernel (row A0) spills nothing
     body8, tail8 = _find(product_asm, "spectrum_kernel<4096, 1, 8, 1>")
     assert _resource(tail8, "ScratchSize") == 0 and _resource(tail8, "Occupancy") == 3
