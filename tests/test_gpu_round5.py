@@ -160,3 +160,58 @@ def test_bench_rehearsal_lines_say_so_and_name_their_backend():
     assert d["config"]["collective"].startswith("gloo") and "RCCL" not in d["config"]["collective"]
     e = _bench(["--config", "4", "--inprocess", "--gpus", "2", "--passes", "4", "--steps", "2", "--warmup", "1"])
     assert e["value_is_rehearsal"] is True
+
+
+# ------------------------------------------------------------------------------- error paths leave nothing behind
+def test_read_view_refuses_before_it_enqueues_and_zeroes_found(ksa, torch_cuda):
+    """ksa_read_view on an engine without a waterfall (hm_width 0 is impossible through SpectrumEngine, so: the scan ring of an
+    engine created without scan geometry, and a row count outside the ring) fails BEFORE its first asynchronous copy -- the
+    caller's buffers are untouched -- and a call without markers reports found = 0."""
+    import ctypes as C
+    n, full = 1024, 8192
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, xres=256, max_frames=4)
+    x = orc.synth_iq(full * 4, 3).astype(np.complex64).reshape(4, full)
+    for f in range(4):
+        eng.frame(x[f])
+    lib = ksa.lib
+    lv = np.full((4, 256), 7.0, dtype=np.float32)
+    rows = np.full((2, 256), 7.0, dtype=np.float32)
+    found, hm_index = C.c_int32(99), C.c_int32(-5)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    # scan view on an engine without scan geometry
+    rc = lib.ksa_read_view(eng._h, 1, 0, 256, vp(lv), 0, 0.0, 0, None, None, C.byref(found), 2, vp(rows), C.byref(hm_index))
+    assert rc != 0 and b"scan" in lib.ksa_last_error()
+    assert np.all(lv == 7.0) and np.all(rows == 7.0)
+    # more rows than the ring has
+    rc = lib.ksa_read_view(eng._h, 0, 0, 256, vp(lv), 0, 0.0, 0, None, None, C.byref(found), 129, vp(rows), C.byref(hm_index))
+    assert rc != 0 and np.all(lv == 7.0) and np.all(rows == 7.0)
+    # a good call without markers: found is written (0), the rows arrive
+    found.value = 99
+    rc = lib.ksa_read_view(eng._h, 0, 0, 256, vp(lv), 0, 0.0, 0, None, None, C.byref(found), 2, vp(rows), C.byref(hm_index))
+    assert rc == 0 and found.value == 0 and hm_index.value == 4
+    assert np.array_equal(rows.astype(np.float64), eng.state()["fftHM"][[2, 3]]) and not np.all(lv == 7.0)
+    eng.close()
+
+
+def test_abandoned_band_sharded_batch_does_not_block_the_next_allstitch(ksa, torch_cuda):
+    """ksa_scan_allstitch refuses while an engine still holds unmerged partial rows (scan_rows > 0).  A batch abandoned after
+    ksa_scan_stitch_range_dev used to leave that flag set for ever; ksa_scan_reset clears it now, and so does a failing
+    allstitch on its way out."""
+    torch = torch_cuda
+    n, full = 256, 2048
+    mk = lambda: ksa.SpectrumEngine(n, full_size=full, non_overlap=0.5, window="hanning", gain=GAIN, min_amp=1e-7, xres=64,
+                                    max_frames=16, scan_total_entries=2 * n)
+    a, b = mk(), mk()
+    steps, passes = 4, 2
+    own = torch.full((passes, 2, n), -40.0, dtype=torch.float32, device="cuda")
+    # engine a stitches its range alone and never merges the rows: the batch is abandoned
+    lo, hi, nhalo, e_lo, e_hi = a.scan_shard(steps, 0, 2)
+    a.scan_stitch_range_dev(own, None, 0, lo, hi, steps, passes, e_lo, e_hi)
+    with pytest.raises(ksa.KsaError, match="unmerged partial rows"):
+        ksa.scan_allstitch([a, b], [own, own], steps, passes)
+    a.scan_reset()
+    b.scan_reset()
+    ksa.scan_allstitch([a, b], [own, own], steps, passes)
+    assert a.scan_state()["passes"] == passes and b.scan_state()["passes"] == passes
+    for e in (a, b):
+        e.close()
