@@ -150,7 +150,12 @@ def test_random_scan(ksa, case):
         eng.scan_pass_dev(torch.view_as_real(torch.from_numpy(x)).cuda(), ksa.FMT_C64, steps, step_ok=ok)
     st = eng.scan_state()
     assert st["passes"] == passes and st["hm_index"] == ref.hm_index
+    # The four curves are dB-domain mixtures of the bands' bins (K:643-668): Min in particular may hold no strong bin at all, so
+    # the linear comparison is normalised by the strongest value behind them -- the maximum of the oracle's Max curve -- the
+    # north star's max|X| (a 500-case soak with seed 123 found 1.1e-5 of the Min curve's OWN maximum at a bin 30 dB below the
+    # spectra's peak: 3e-8 of that peak, i.e. plain fp32 transform noise).
+    top = float(np.max(10 ** (ref.max[np.isfinite(ref.max)] / 10)))
     for k in ("cur", "max", "min", "avg"):
-        assert_db(st["Fft." + k.capitalize()], getattr(ref, k), what="scan " + k)
+        assert_db(st["Fft." + k.capitalize()], getattr(ref, k), what="scan " + k, top=top)
     assert_db(st["fftHM"][:min(passes, 128)], ref.hm[:min(passes, 128)], what="scan waterfall")
     eng.close()
