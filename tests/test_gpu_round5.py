@@ -101,6 +101,41 @@ def _engine(ksa, n, full, q, frames, **kw):
     return ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning", gain=GAIN, xres=512, max_frames=frames, **kw)
 
 
+@pytest.mark.parametrize("tag", ["3band_n512", "dummy_n512"])
+def test_integration_section4_runs_verbatim_against_the_scan_goldens(ksa, torch_cuda, tag):
+    """Section 4 -- the body of the reference's step loop K:621-668 + the row of K:696-697 as "capture the pass, hand it over"
+    (host pointers, ksa_scan_pass_c64) -- executed verbatim once per pass against the reference's own scans: a three-band scan,
+    and one with failed tunes (sdr_setup returning False -> the dummy ones band, K:637-639)."""
+    import ctypes as C
+    from test_gpu_round2 import _regen_iq
+    g = golden("scan_" + tag)
+    n, full, passes, steps = int(g["fft_size"]), int(g["full"]), int(g["passes"]), int(g["steps"])
+    step_ok = g["step_ok"].astype(bool) if "step_ok" in g.files else np.ones((passes, steps), dtype=bool)
+    # the stream the reference consumed: one block per SUCCESSFUL tune, in order (a failed tune reads nothing, K:635-639)
+    stream = (g["iq"] if "iq" in g.files else _regen_iq(g, full * int(step_ok.sum()))).reshape(-1, full)
+    reads = iter(stream)
+    groups = int((float(g["end_freq"]) - float(g["start_freq"])) / float(g["sampling_rate"]))
+    total = groups * n
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=float(g["non_overlap"]), window=str(g["window"]), gain=float(g["gain"]),
+                             min_amp=float(g["min_amp"]), xres=int(g["xres"]), max_frames=steps, scan_total_entries=total,
+                             scan_non_overlap=float(g["scan_non_overlap"]))
+    body = compile(integration_blocks()["4"][0], "INTEGRATION.md#4", "exec")
+    d = {"fullSize": full, "samplingRate": float(g["sampling_rate"]), "gain": float(g["gain"]), "xRes": int(g["xres"]), "sdr": object(),
+         "ksa": eng._h}
+    for p in range(passes):
+        tunes = iter(step_ok[p])
+        ns = {"np": np, "C": C, "ksa": ksa.lib, "d": d, "total": total, "centers": list(range(steps)),
+              "sdr_setup": lambda sdr, fc, fs, gain: bool(next(tunes)),           # K:630: False = the tune failed
+              "sdr_read": lambda sdr, length: next(reads).astype(np.complex128),   # K:636 reads only after a good tune
+              "prg_quit": lambda dd, msg: (_ for _ in ()).throw(_Quit(msg))}
+        exec(body, ns)
+    for k in CURVES:
+        assert_db(d[k], g[k.replace("Fft.", "").lower()], what="INTEGRATION section 4 %s %s" % (tag, k))
+    assert_db(d["fftHM"][:passes], g["hm"][:passes], what="INTEGRATION section 4 waterfall")
+    assert ns["idx"].value == int(g["hm_index"]) and ns["passes"].value == passes
+    eng.close()
+
+
 # ------------------------------------------------------------------------------- live shader clock (ksa_prof_clock)
 def test_prof_clock_reports_the_clock_held_under_the_stage(ksa, torch_cuda):
     """VERDICT r04 item 4.  Stamp kernels around each profiled spectrum stage read s_memtime / s_memrealtime per XCD; the median
