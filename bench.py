@@ -395,6 +395,8 @@ def roofline_block(cfg, args, eng, units_per_step, kern_ms, launches, step_s):
         kernel = "ksa::dif16_kernel<%s> + ksa::spectrum_kernel<%d,c64> + ksa::dif16_finish_kernel (N = 16*%d)" % (args.fmt, n // 16, n // 16)
     elif info["path"] == 4:
         kernel = "ksa::spectrum_pair_kernel<%d,%s> (two frames per workgroup, packed fp32)" % (n, args.fmt)
+    elif info["path"] == 5 and args.fmt == "c64":
+        kernel = "ksa::spectrum64_kernel<c64> (8 x 8, adjacent-sample loads)"
     elif info["path"] == 3:
         kernel = "ksa::spectrum32_kernel<%d,%s>" % (n, args.fmt)
     else:

@@ -257,7 +257,9 @@ int ksa_kernel_info(ksa_engine* e, int32_t* threads, int32_t* lds_bytes, int32_t
                                                     stage + single-workgroup FFT of N/16 (N = 32768 .. 262144), N/32
                                                     (524288) or N/64 (1048576) points; 4 = N = 1024 .. 4096: large
                                                     batches run two frames per workgroup in packed fp32 (lds / vgprs /
-                                                    grid then describe that kernel), small ones the path-0 kernel */);
+                                                    grid then describe that kernel), small ones the path-0 kernel;
+                                                    5 = N = 64: complex64 input runs the 8 x 8 plan with adjacent-sample
+                                                    loads (lds / vgprs / grid describe it), uint8 input the path-0 kernel */);
 
 #ifdef __cplusplus
 }

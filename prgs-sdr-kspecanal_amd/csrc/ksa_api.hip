@@ -16,6 +16,7 @@
 #include "ksa_dif16.hpp"
 #include "ksa_kernels.hpp"
 #include "ksa_kernels32.hpp"
+#include "ksa_kernels64.hpp"
 #include "ksa_kernels_pair.hpp"
 
 namespace {
@@ -149,6 +150,9 @@ struct ksa_engine {
   // 1024 .. 4096, large batches: two frames per workgroup in packed fp32 (ksa_kernels_pair.hpp)
   bool pair_ok = false;
   int pair_bpc = 0, pair_vgprs = 0, pair_lds = 0;
+  // N = 64, complex64: the 8 x 8 plan with adjacent-sample loads (ksa_kernels64.hpp)
+  bool k64_ok = false;
+  int k64_bpc = 0, k64_vgprs = 0;
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -336,6 +340,38 @@ int launch_spec32(ksa_engine* e, const SpecParams& p, bool cfg_only) {
   return launch_spec32_c<N, FMT, ksa::CUMU_MIN>(e, p, false);
 }
 
+// N = 64, complex64 input: 8 x 8 with adjacent samples per lane (ksa_kernels64.hpp)
+template <int CM>
+int launch_spec64_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
+  auto kfn = ksa::spectrum64_kernel<ksa::FMT_C64, CM>;
+  if (configure_only) {
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, ksa::Plan64::LDS_BYTES));
+    int occ = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, ksa::Plan64::T, ksa::Plan64::LDS_BYTES));
+    if (CM == ksa::CUMU_AVG) {
+      hipFuncAttributes attr;
+      HIP_OK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kfn)));
+      e->k64_bpc = std::max(1, occ);
+      e->k64_vgprs = attr.numRegs;
+    }
+    return 0;
+  }
+  const int grid = std::max(1, std::min(p.nframes, e->num_cu * e->k64_bpc));
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(ksa::Plan64::T), ksa::Plan64::LDS_BYTES, e->stream, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_spec64(ksa_engine* e, const SpecParams& p, bool cfg_only) {
+  if (cfg_only) {
+    if (launch_spec64_c<ksa::CUMU_MAX>(e, p, true) || launch_spec64_c<ksa::CUMU_MIN>(e, p, true)) return 1;
+    return launch_spec64_c<ksa::CUMU_AVG>(e, p, true);
+  }
+  if (p.cumu == ksa::CUMU_AVG) return launch_spec64_c<ksa::CUMU_AVG>(e, p, false);
+  if (p.cumu == ksa::CUMU_MAX) return launch_spec64_c<ksa::CUMU_MAX>(e, p, false);
+  return launch_spec64_c<ksa::CUMU_MIN>(e, p, false);
+}
+
 template <int FMT>
 int launch_spec_n(ksa_engine* e, const SpecParams& p, bool cfg_only) {
   const int rm = p.nwin > 1 ? e->reuse_m : 0;   // RAW mode transforms a single window: nothing to reuse
@@ -343,7 +379,14 @@ int launch_spec_n(ksa_engine* e, const SpecParams& p, bool cfg_only) {
   switch (e->sub_n) {
     case 16: return launch_spec_rm<16, FMT>(e, p, cfg_only, rm);
     case 32: return launch_spec_rm<32, FMT>(e, p, cfg_only, rm);
-    case 64: return launch_spec_rm<64, FMT>(e, p, cfg_only, rm);
+    case 64:
+      if constexpr (FMT == ksa::FMT_C64) {
+        if (e->k64_ok) {
+          if (cfg_only) { if (launch_spec64(e, p, true)) return 1; }     // (then the general kernel's attributes too: uint8 input runs it)
+          else if (!exp_env("KSA_NO_K64")) return launch_spec64(e, p, false);
+        }
+      }
+      return launch_spec_rm<64, FMT>(e, p, cfg_only, rm);
     case 128: return launch_spec_rm<128, FMT>(e, p, cfg_only, rm);
     case 256: return launch_spec_rm<256, FMT>(e, p, cfg_only, rm);
     case 512: return launch_spec_rm<512, FMT>(e, p, cfg_only, rm);
@@ -748,6 +791,16 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
           for (int j = 0; j < 4; ++j)
             w32[((size_t)q4 * lth + l) * 4 + j] = e->path == 0 ? cfg->window[l + lth * (4 * q4 + j)] : 1.0f;
       if ((rc = upload(&e->d_window32, w32.data(), w32.size()))) return bail(rc);
+    }
+    if (sn == 64 && e->path == 0) {
+      // the 8 x 8 plan of N = 64 (ksa_kernels64.hpp): W64^(m k1) as [m][k1]; the 4 x 16 plan has no middle pass, the slot is free
+      e->k64_ok = true;
+      mid.resize(64);
+      for (int mm = 0; mm < 8; ++mm)
+        for (int k1 = 0; k1 < 8; ++k1) {
+          const double ang = -2.0 * M_PI * (double)(mm * k1) / 64.0;
+          mid[(size_t)mm * 8 + k1] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
     }
     if ((rc = upload(&e->d_tw_mid, mid.data(), mid.size()))) return bail(rc);
     if ((rc = upload(&e->d_tw_last, last.data(), last.size()))) return bail(rc);
@@ -1685,7 +1738,12 @@ int ksa_kernel_info(ksa_engine* e, int32_t* threads, int32_t* lds_bytes, int32_t
   if (lds_bytes) *lds_bytes = e->lds_bytes;
   if (vgprs) *vgprs = e->vgprs;
   if (grid) *grid = e->num_cu * e->blocks_per_cu;
-  if (path) *path = (e->path == 0 && e->plan32) ? 3 : (e->path == 0 && e->pair_ok) ? 4 : e->path;
+  if (path) *path = (e->path == 0 && e->plan32) ? 3 : (e->path == 0 && e->pair_ok) ? 4 : (e->path == 0 && e->k64_ok) ? 5 : e->path;
+  if (e->path == 0 && e->k64_ok) {            // what complex64 input runs
+    if (lds_bytes) *lds_bytes = ksa::Plan64::LDS_BYTES;
+    if (vgprs) *vgprs = e->k64_vgprs;
+    if (grid) *grid = e->num_cu * e->k64_bpc;
+  }
   if (e->path == 0 && e->pair_ok) {           // what large batches run
     if (lds_bytes) *lds_bytes = e->pair_lds;
     if (vgprs) *vgprs = e->pair_vgprs;

@@ -1,0 +1,179 @@
+// spectrum64_kernel: the 64-point transform (quickFullScan's fftSize, K:916-921) as 8 x 8 with ADJACENT samples per lane.
+//
+// Same rows of SURVEY.md section 8 as spectrum_kernel (A4-A9, A12; replaces numpy.fft.fft + the fold at
+// python/kspecanal.py:385-396) and the same workgroup shape (one wave = 16 transforms of 4 lanes, 16 points per lane), but a
+// different split of the DFT.  spectrum_kernel<64> is 4 x 16: lane l owns samples l + 4q and needs sixteen 8-byte loads per
+// round whose quads point at 16 different places; the cycle stamps put half of a wave's time into issuing and awaiting them
+// (profiles/r05_c4_stamps_issue.txt), and tools/ta_probe.hip prices that shape at 2.48 us per round per CU against 1.70 us
+// for eight 16-byte loads of adjacent samples (profiles/r05_ta_probe.txt).  Here lane l owns samples n = 8j + 2l + c
+// (j = 0..7, c = 0,1 -- each load is two adjacent samples), and with k = k1 + 8 k2:
+//
+//   X[k1 + 8 k2] = sum_m W8^(m k2) * { W64^(m k1) * sum_j x[8j + m] W8^(j k1) },   m = 2l + c
+//
+//   A  two radix-8 butterflies per lane over j (no twiddles, window multiply in front),
+//   B  the 14 twiddles W64^(m k1) of a lane (per-lane constants, float64-generated table),
+//   -- one exchange through LDS inside the slot (element (k1, m) at k1*8 + (m ^ k1): the XOR keeps both sides off each
+//      other's banks without padding rows) --
+//   C  two radix-8 butterflies per lane over m (no twiddles): lane l' ends with bins (2l' + c') + 8 k2.
+//
+// Measured against spectrum_kernel<64> in one build (profiles/r05_ab_k64.txt): config 4 +3.6 ... +5.5 % on three boxes, N = 64 at
+// hops 0.5 / 0.25 / 0.1 +2 ... +10 %.  Variants on top: 3 waves per SIMD without spills = the old kernel's speed; all 14 twiddles
+// in VGPRs (19 spilled registers at the 128-VGPR cap of four waves per SIMD) -0.5 %; the exchange as 8 + 8 16-byte operations
+// on plain rows +-0.  uint8 input keeps spectrum_kernel<64> (its two-sample piece is a 4-byte load at 2-byte alignment).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ksa_kernels.hpp"
+
+namespace ksa {
+
+struct Plan64 {
+  static constexpr int N = 64, T = 64, S = 16, L = 4;
+  static constexpr int XS = 68;                            // complex elements per slot (64 + 4: slots off each other's banks)
+  static constexpr int LDS_BYTES = S * XS * 8 + N * 4;     // exchange / staging rows + taps
+};
+
+#ifndef KSA64_WPS
+#define KSA64_WPS 4      // waves per SIMD the register allocator leaves room for (A/B builds: 3 = 168 VGPRs, no spills)
+#endif
+template <int FMT, int CM>
+__global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecParams p) {
+  static_assert(FMT == FMT_C64, "adjacent-sample loads: complex64 input (16-byte loads of two samples)");
+  using P = Plan64;
+  constexpr int N = P::N, T = P::T, S = P::S;
+  constexpr int SB = 8;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  float* const taps_lds = reinterpret_cast<float*>(lds + S * P::XS);
+  const int tid = threadIdx.x, slot = tid >> 2, l = tid & 3;
+  float2* const my = lds + slot * P::XS;
+
+  // taps in the lanes' load order: lane l' needs w[8j + 2l' + c] for j = 0..7, c = 0,1 -> taps_lds[l'*16 + 2j + c]
+  {
+    const int n = tid, lp = (n & 7) >> 1, c = n & 1, j = n >> 3;
+    taps_lds[lp * 16 + 2 * j + c] = p.window[n];
+  }
+  // step B: W64^(m k1), m = 2l + c, k1 = 1..7 (p.tw_mid = [m][k1], generated in float64 on the host)
+#ifndef KSA64_TW_HALF
+#define KSA64_TW_HALF 1  // 1: only the even samples' twiddles W64^(2l k1) live in VGPRs, the odd ones' are those times the constants W64^k1
+#endif
+  float2 twb[KSA64_TW_HALF ? 1 : 2][7];
+#pragma unroll
+  for (int c = 0; c < (KSA64_TW_HALF ? 1 : 2); ++c)
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) twb[c][k1 - 1] = p.tw_mid[(2 * l + c) * 8 + k1];
+  __syncthreads();
+
+  const int nm1 = p.nwin - 1;
+  const int rounds = (p.nwin + S - 1) / S;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  for (int frame = blockIdx.x; frame < p.nframes; frame += gridDim.x) {
+    float acc[16];
+    const float init = p.cumu == CUMU_MIN ? __builtin_inff() : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = init;
+    const char* fbase = reinterpret_cast<const char*>(p.iq) + (long long)frame * p.frame_stride * SB;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fbase), 0, p.frame_len * SB, 0x00020000);
+
+    for (int rd = 0; rd < rounds; ++rd) {
+      const int k = rd * S + slot;
+      const bool active = k < p.nwin;
+      float2 v[16];            // v[c*8 + j] = x[8j + 2l + c] * w
+      if (active) {
+        const int voff = (p.starts[k] + 2 * l) * SB;
+        u32x4 piece[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) piece[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 8 * j * SB, 0);
+#ifndef KSA64_TAPS
+#define KSA64_TAPS 1     // 1: the two taps of a 16-byte piece are read (ds_read_b64) right where the piece is converted; 0: four ds_read_b128 up front
+#endif
+#if KSA64_TAPS
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float2 w2 = reinterpret_cast<const float2*>(taps_lds)[l * 8 + j];
+          const unsigned a = piece[j].x, b = piece[j].y, c = piece[j].z, d = piece[j].w;   // (scalar copies: see spectrum_kernel)
+          v[j] = make_float2(__uint_as_float(a) * w2.x, __uint_as_float(b) * w2.x);
+          v[8 + j] = make_float2(__uint_as_float(c) * w2.y, __uint_as_float(d) * w2.y);
+        }
+#else
+        float w[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 w4 = reinterpret_cast<const float4*>(taps_lds)[l * 4 + q4];
+          w[4 * q4 + 0] = w4.x; w[4 * q4 + 1] = w4.y; w[4 * q4 + 2] = w4.z; w[4 * q4 + 3] = w4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned a = piece[j].x, b = piece[j].y, c = piece[j].z, d = piece[j].w;   // (scalar copies: see spectrum_kernel)
+          v[j] = make_float2(__uint_as_float(a) * w[2 * j], __uint_as_float(b) * w[2 * j]);
+          v[8 + j] = make_float2(__uint_as_float(c) * w[2 * j + 1], __uint_as_float(d) * w[2 * j + 1]);
+        }
+#endif
+        dft8<0>(v);            // position c*8 + P holds y_m[perm8(P)]
+        dft8<8>(v);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int Pp = 1; Pp < 8; ++Pp) {
+#if KSA64_TW_HALF
+            constexpr float cw[8] = {1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f, 0.92387953251128675613f,
+                                     0.88192126434835502971f, 0.83146961230254523708f, 0.77301045336273696081f};
+            constexpr float sw[8] = {0.0f, 0.09801714032956060199f, 0.19509032201612826785f, 0.29028467725446236764f, 0.38268343236508977173f,
+                                     0.47139673682599764856f, 0.55557023301960222474f, 0.63439328416364549822f};
+            float2 y = v[c * 8 + Pp];
+            if (c == 1) y = cmul(y, make_float2(cw[perm<8>(Pp)], -sw[perm<8>(Pp)]));      // W64^k1
+            v[c * 8 + Pp] = cmul(y, twb[0][perm<8>(Pp) - 1]);
+#else
+            v[c * 8 + Pp] = cmul(v[c * 8 + Pp], twb[c][perm<8>(Pp) - 1]);
+#endif
+          }
+      }
+      __syncthreads();         // (single-wave workgroup: orders the previous round's reads before these stores)
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int Pp = 0; Pp < 8; ++Pp) {
+            const int k1 = perm<8>(Pp);
+            my[k1 * 8 + ((2 * l + c) ^ k1)] = v[c * 8 + Pp];
+          }
+      }
+      __syncthreads();
+      if (active) {
+        float2 u[16];          // u[c'*8 + m] = z_m[k1], k1 = 2l + c'
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int m = 0; m < 8; ++m) u[c * 8 + m] = lds_ld64(&my[(2 * l + c) * 8 + (m ^ (2 * l + c))]);
+
+        dft8<0>(u);            // position c'*8 + P holds X[(2l + c') + 8*perm8(P)]
+        dft8<8>(u);
+        const int cm = CM == 0 ? p.cumu : CM;
+        if (cm == CUMU_AVG) {
+          const int e = k == 0 ? nm1 : nm1 - k + 1;          // closed form of the (a+x)/2 recursion (K:137-139 at K:395)
+          const float wgt = ldexpf(1.0f, -e);
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            acc[i] = fmaf(wgt, __builtin_amdgcn_sqrtf(fmaf(u[i].x, u[i].x, u[i].y * u[i].y)), acc[i]);
+        } else if (cm == CUMU_MAX) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = nan_max_nonneg(acc[i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = nan_min(acc[i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
+        }
+      }
+    }
+    // natural bin order through LDS, then the common output stage: acc[c'*8 + P] is bin (2l + c') + 8*perm8(P)
+    float* const red = reinterpret_cast<float*>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int Pp = 0; Pp < 8; ++Pp) red[slot * RedStride<N, S>::value + (2 * l + c) + 8 * perm<8>(Pp)] = acc[c * 8 + Pp];
+    __syncthreads();
+    finish_frame<N, T, S, CM>(p, red, frame, tid);
+  }
+}
+
+}  // namespace ksa

@@ -40,7 +40,7 @@ for k, c in out.items():
 json.dump({"bench_line": bench, "bench_args": open(os.path.join(src, "bench_args.txt")).read().strip() if os.path.exists(os.path.join(src, "bench_args.txt")) else "",
            "kernels": out}, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 # dominant kernels = the spectrum stage: spectrum_kernel (+ combine_parts) or the four-step kernels
-dom = {k: c for k, c in out.items() if any(s in k for s in ("spectrum_kernel", "spectrum_pair_kernel", "spectrum32_kernel", "combine_parts", "dif16_", "dif_wide_")) and "hbm_bytes_per_launch" in c}
+dom = {k: c for k, c in out.items() if any(s in k for s in ("spectrum_kernel", "spectrum_pair_kernel", "spectrum32_kernel", "spectrum64_kernel", "combine_parts", "dif16_", "dif_wide_")) and "hbm_bytes_per_launch" in c}
 if dom and bench:
     import bench as B
     cfg = bench["config"]
