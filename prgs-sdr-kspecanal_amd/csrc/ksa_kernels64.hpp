@@ -66,6 +66,11 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
 
   const int nm1 = p.nwin - 1;
   const int rounds = (p.nwin + S - 1) / S;
+#ifdef KSA_STAMPS
+  unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   for (int frame = blockIdx.x; frame < p.nframes; frame += gridDim.x) {
     float acc[16];
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
         u32x4 piece[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) piece[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 8 * j * SB, 0);
+        KSA_STAMP(11);
 #ifndef KSA64_TAPS
 #define KSA64_TAPS 1     // 1: the two taps of a 16-byte piece are read (ds_read_b64) right where the piece is converted; 0: four ds_read_b128 up front
 #endif
@@ -109,6 +115,7 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
           v[8 + j] = make_float2(__uint_as_float(c) * w[2 * j + 1], __uint_as_float(d) * w[2 * j + 1]);
         }
 #endif
+        KSA_STAMP(0);
         dft8<0>(v);            // position c*8 + P holds y_m[perm8(P)]
         dft8<8>(v);
 #pragma unroll
@@ -128,6 +135,7 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
 #endif
           }
       }
+      KSA_STAMP(1);
       __syncthreads();         // (single-wave workgroup: orders the previous round's reads before these stores)
       if (active) {
 #pragma unroll
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
           }
       }
       __syncthreads();
+      KSA_STAMP(3);
       if (active) {
         float2 u[16];          // u[c'*8 + m] = z_m[k1], k1 = 2l + c'
 #pragma unroll
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
 
         dft8<0>(u);            // position c'*8 + P holds X[(2l + c') + 8*perm8(P)]
         dft8<8>(u);
+        KSA_STAMP(6);
         const int cm = CM == 0 ? p.cumu : CM;
         if (cm == CUMU_AVG) {
           const int e = k == 0 ? nm1 : nm1 - k + 1;          // closed form of the (a+x)/2 recursion (K:137-139 at K:395)
@@ -163,6 +173,7 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
           for (int i = 0; i < 16; ++i) acc[i] = nan_min(acc[i], fmaf(u[i].x, u[i].x, u[i].y * u[i].y));
         }
       }
+      KSA_STAMP(7);
     }
     // natural bin order through LDS, then the common output stage: acc[c'*8 + P] is bin (2l + c') + 8*perm8(P)
     float* const red = reinterpret_cast<float*>(lds);
@@ -172,8 +183,14 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
 #pragma unroll
       for (int Pp = 0; Pp < 8; ++Pp) red[slot * RedStride<N, S>::value + (2 * l + c) + 8 * perm<8>(Pp)] = acc[c * 8 + Pp];
     __syncthreads();
+    KSA_STAMP(10);
     finish_frame<N, T, S, CM>(p, red, frame, tid);
+    KSA_STAMP(8);
   }
+#ifdef KSA_STAMPS
+  if (p.dbg && tid == 0)
+    for (int i = 0; i < 12; ++i) p.dbg[(long long)blockIdx.x * 12 + i] = seg[i];
+#endif
 }
 
 }  // namespace ksa
