@@ -304,8 +304,9 @@ def limiter_sentence(config, rf):
            "LDS exchanges running in series at 3 waves per SIMD",
         3: "90 %% window overlap: every sample is transformed ten times, one workgroup of 135 KB of LDS per CU at 2 waves per SIMD; HBM sees "
            "%.2f of its peak, fp32 %.2f of the vector peak",
-        4: "90 %% window overlap at N = 64: 16 transforms per wave, half of a wave's time goes into issuing and awaiting the 16 scattered "
-           "8-byte loads of a round (cycle stamps, profiles/r05_c4_stamps_issue.txt); HBM sees %.2f of its peak, fp32 %.2f of the vector peak",
+        4: "90 %% window overlap at N = 64: 16 transforms per wave (8 x 8 plan), more than a third of a wave's time goes into issuing and awaiting "
+           "the 8 adjacent-sample 16-byte loads of a round, a fifth into the exchange through LDS (cycle stamps, profiles/r05_c4_stamps_k64.txt); "
+           "HBM sees %.2f of its peak, fp32 %.2f of the vector peak",
         5: "two streaming passes over the first-stage scratch Z: HBM sees %.2f of its peak in algorithmic bytes, fp32 %.2f of the vector peak",
     }[config] % (rf["frac"], rf["flop_frac"])
     return head + "; " + pipes
