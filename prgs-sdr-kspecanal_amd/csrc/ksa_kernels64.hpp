@@ -16,10 +16,14 @@
 //      other's banks without padding rows) --
 //   C  two radix-8 butterflies per lane over m (no twiddles): lane l' ends with bins (2l' + c') + 8 k2.
 //
-// Measured against spectrum_kernel<64> in one build (profiles/r05_ab_k64.txt): config 4 +3.6 ... +5.5 % on three boxes, N = 64 at
-// hops 0.5 / 0.25 / 0.1 +2 ... +10 %.  Variants on top: 3 waves per SIMD without spills = the old kernel's speed; all 14 twiddles
-// in VGPRs (19 spilled registers at the 128-VGPR cap of four waves per SIMD) -0.5 %; the exchange as 8 + 8 16-byte operations
-// on plain rows +-0.  uint8 input keeps spectrum_kernel<64> (its two-sample piece is a 4-byte load at 2-byte alignment).
+// Measured against spectrum_kernel<64> in one build (profiles/r05_ab_k64.txt): config 4 +3.6 ... +5.6 % on four boxes, N = 64 at
+// hops 0.5 / 0.25 +1 ... +10 %.  Variants on top, measured and removed: 3 waves per SIMD without spills = the old kernel's speed;
+// all 14 twiddles in VGPRs (19 spilled registers at the 128-VGPR cap of four waves per SIMD) -0.5 %; taps as four ds_read_b128
+// up front -0.8 %; the exchange as 8 + 8 16-byte operations on plain rows +-0; odd slots one element later (conflict-free in
+// the bank model; the kept layout shows a conflict ratio of 0.41 in the counters) -0.8 %: the conflicts are not on a wave's
+// critical path.  Where a wave's time goes (-DKSA_STAMPS, profiles/r05_c4_stamps_k64.txt): load issue 22 %, wait + taps +
+// multiply 16 %, A + B 12 %, exchange 18 %, reads + C 10 %, fold 9 %, output stage 13 %.
+// uint8 input keeps spectrum_kernel<64> (its two-sample piece is a 4-byte load at 2-byte alignment).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,11 +38,8 @@ struct Plan64 {
   static constexpr int LDS_BYTES = S * XS * 8 + N * 4;     // exchange / staging rows + taps
 };
 
-#ifndef KSA64_WPS
-#define KSA64_WPS 4      // waves per SIMD the register allocator leaves room for (A/B builds: 3 = 168 VGPRs, no spills)
-#endif
 template <int FMT, int CM>
-__global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecParams p) {
+__global__ __launch_bounds__(64, 4) void spectrum64_kernel(const SpecParams p) {
   static_assert(FMT == FMT_C64, "adjacent-sample loads: complex64 input (16-byte loads of two samples)");
   using P = Plan64;
   constexpr int N = P::N, T = P::T, S = P::S;
@@ -54,14 +55,10 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
     taps_lds[lp * 16 + 2 * j + c] = p.window[n];
   }
   // step B: W64^(m k1), m = 2l + c, k1 = 1..7 (p.tw_mid = [m][k1], generated in float64 on the host)
-#ifndef KSA64_TW_HALF
-#define KSA64_TW_HALF 1  // 1: only the even samples' twiddles W64^(2l k1) live in VGPRs, the odd ones' are those times the constants W64^k1
-#endif
-  float2 twb[KSA64_TW_HALF ? 1 : 2][7];
+  // only the EVEN samples' twiddles W64^(2l k1) live in VGPRs; the odd samples' are those times the constants W64^k1 below
+  float2 twb[7];
 #pragma unroll
-  for (int c = 0; c < (KSA64_TW_HALF ? 1 : 2); ++c)
-#pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) twb[c][k1 - 1] = p.tw_mid[(2 * l + c) * 8 + k1];
+  for (int k1 = 1; k1 < 8; ++k1) twb[k1 - 1] = p.tw_mid[(2 * l) * 8 + k1];
   __syncthreads();
 
   const int nm1 = p.nwin - 1;
@@ -90,31 +87,13 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
 #pragma unroll
         for (int j = 0; j < 8; ++j) piece[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 8 * j * SB, 0);
         KSA_STAMP(11);
-#ifndef KSA64_TAPS
-#define KSA64_TAPS 1     // 1: the two taps of a 16-byte piece are read (ds_read_b64) right where the piece is converted; 0: four ds_read_b128 up front
-#endif
-#if KSA64_TAPS
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 8; ++j) {    // the two taps of a piece are read (ds_read_b64) right where the piece is converted
           const float2 w2 = reinterpret_cast<const float2*>(taps_lds)[l * 8 + j];
           const unsigned a = piece[j].x, b = piece[j].y, c = piece[j].z, d = piece[j].w;   // (scalar copies: see spectrum_kernel)
           v[j] = make_float2(__uint_as_float(a) * w2.x, __uint_as_float(b) * w2.x);
           v[8 + j] = make_float2(__uint_as_float(c) * w2.y, __uint_as_float(d) * w2.y);
         }
-#else
-        float w[16];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const float4 w4 = reinterpret_cast<const float4*>(taps_lds)[l * 4 + q4];
-          w[4 * q4 + 0] = w4.x; w[4 * q4 + 1] = w4.y; w[4 * q4 + 2] = w4.z; w[4 * q4 + 3] = w4.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const unsigned a = piece[j].x, b = piece[j].y, c = piece[j].z, d = piece[j].w;   // (scalar copies: see spectrum_kernel)
-          v[j] = make_float2(__uint_as_float(a) * w[2 * j], __uint_as_float(b) * w[2 * j]);
-          v[8 + j] = make_float2(__uint_as_float(c) * w[2 * j + 1], __uint_as_float(d) * w[2 * j + 1]);
-        }
-#endif
         KSA_STAMP(0);
         dft8<0>(v);            // position c*8 + P holds y_m[perm8(P)]
         dft8<8>(v);
@@ -122,17 +101,13 @@ __global__ __launch_bounds__(64, KSA64_WPS) void spectrum64_kernel(const SpecPar
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int Pp = 1; Pp < 8; ++Pp) {
-#if KSA64_TW_HALF
             constexpr float cw[8] = {1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f, 0.92387953251128675613f,
                                      0.88192126434835502971f, 0.83146961230254523708f, 0.77301045336273696081f};
             constexpr float sw[8] = {0.0f, 0.09801714032956060199f, 0.19509032201612826785f, 0.29028467725446236764f, 0.38268343236508977173f,
                                      0.47139673682599764856f, 0.55557023301960222474f, 0.63439328416364549822f};
             float2 y = v[c * 8 + Pp];
             if (c == 1) y = cmul(y, make_float2(cw[perm<8>(Pp)], -sw[perm<8>(Pp)]));      // W64^k1
-            v[c * 8 + Pp] = cmul(y, twb[0][perm<8>(Pp) - 1]);
-#else
-            v[c * 8 + Pp] = cmul(v[c * 8 + Pp], twb[c][perm<8>(Pp) - 1]);
-#endif
+            v[c * 8 + Pp] = cmul(y, twb[perm<8>(Pp) - 1]);
           }
       }
       KSA_STAMP(1);
