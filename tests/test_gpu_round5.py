@@ -250,3 +250,64 @@ def test_abandoned_band_sharded_batch_does_not_block_the_next_allstitch(ksa, tor
     assert a.scan_state()["passes"] == passes and b.scan_state()["passes"] == passes
     for e in (a, b):
         e.close()
+
+
+# ------------------------------------------------------------------------------------------ the 8 x 8 plan of N = 64
+def test_n64_complex_input_runs_the_8x8_kernel_within_its_register_budget(ksa):
+    """ksa_kernel_info names what complex64 input runs at N = 64: path 5 = spectrum64_kernel (ksa_kernels64.hpp), one wave per
+    workgroup, at most 128 VGPRs (four waves per SIMD) and the LDS of Plan64."""
+    eng = ksa.SpectrumEngine(64, full_size=512, non_overlap=0.1, window="ones")
+    info = eng.kernel_info()
+    assert info["path"] == 5 and info["threads"] == 64 and info["vgprs"] <= 128 and info["lds_bytes"] == 16 * 68 * 8 + 64 * 4
+    eng.close()
+
+
+@pytest.mark.parametrize("full,q", [(64, 0.5), (100, 0.1), (160, 0.5), (512, 0.1), (512, 0.25), (1100, 0.5), (1111, 0.07), (4096, 0.1)])
+def test_n64_8x8_kernel_every_fold_mode_and_round_shape(ksa, torch_cuda, full, q):
+    """spectrum64_kernel against the oracle's curscan (K:351-397) for window counts of 1, one partial round, exact multiples of
+    16, 71 (quickFullScan) and hundreds of windows (many rounds), every fold mode and window; on-bin tone known answer;
+    complex64 and uint8 input of the same samples agree (uint8 runs the 4 x 16 kernel: two plans, one spectrum)."""
+    n = 64
+    starts = orc.window_starts(full, n, q)
+    x = orc.synth_iq(full, 4242 + full).astype(np.complex64)
+    for w, m in (("hanning", "AVG"), ("kaiser", "MAX"), ("ones", "MIN"), ("hamming", "RAW")):
+        eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=w, cumu_mode=m)
+        assert eng.num_windows == len(starts) and eng.kernel_info()["path"] == 5
+        assert_lin(eng.curscan(x), orc.curscan(x, n, q, orc.window_table(w, n), m), what="N=64 full=%d q=%s %s %s" % (full, q, w, m))
+        eng.close()
+    # the same samples as uint8 I,Q (4 x 16 kernel) and as the complex64 values they unpack to (8 x 8 kernel)
+    raw = orc.quantize_u8(x * 0.8)
+    xq = orc.unpack_u8(raw).astype(np.complex64)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="hanning")
+    a, b = eng.curscan(raw), eng.curscan(xq)
+    assert_lin(a, b, tol=2e-6, what="u8 (4 x 16) against c64 (8 x 8)")
+    eng.close()
+    # a tone on bin 19 of 64 under a rectangular window: one bin holds everything (the oracle's value: K:391's 2 / N scale)
+    t = np.exp(2j * np.pi * 19 * np.arange(full) / n).astype(np.complex64)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="ones")
+    y, want = eng.curscan(t), orc.curscan(t, n, q, orc.window_table("ones", n), "AVG")
+    k = int(np.argmax(want))
+    assert int(np.argmax(y)) == k and abs(y[k] - want[k]) < 1e-5 * want[k] and np.max(np.delete(y, k)) < 1e-5 * want[k]
+    eng.close()
+
+
+@pytest.mark.parametrize("frames", [1, 15, 16, 17, 4099])
+def test_n64_8x8_kernel_batches_smaller_and_larger_than_its_grid(ksa, torch_cuda, frames):
+    """frames_dev at N = 64 (complex64): fewer frames than workgroups, one more than a multiple, and more frames than the
+    persistent grid holds -- per-frame dB rows, waterfall rows and the running curves against the oracle's sequential loop."""
+    torch = torch_cuda
+    n, full, q = 64, 512, 0.1
+    x = orc.synth_iq(full * frames, 77 + frames).astype(np.complex64).reshape(frames, full)
+    st_ref, db_ref, _ = orc.zerospan_batch(x, n, q, orc.window_table("kaiser", n), "AVG", GAIN, 64)
+    eng = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="kaiser", gain=GAIN, xres=64, max_frames=frames)
+    cur_db = torch.empty((frames, n), dtype=torch.float32, device="cuda")
+    rows = torch.empty((frames, eng.hm_width), dtype=torch.float32, device="cuda")
+    eng.frames_dev(torch.view_as_real(torch.from_numpy(x)).cuda(), ksa.FMT_C64, frames, cur_db=cur_db, hm_rows=rows)
+    torch.cuda.synchronize()
+    st = eng.state()
+    assert_db(cur_db.cpu().numpy(), db_ref, what="per-frame dB, %d frames" % frames)
+    want_rows = np.array([orc.plotcompress(r, eng.hm_width, "MAX") for r in db_ref])
+    assert_db(rows.cpu().numpy(), want_rows, what="per-frame rows")
+    for k in ("cur", "max", "min", "avg"):
+        assert_db(st["Fft." + k.capitalize()], getattr(st_ref, k), what="N=64 %s" % k)
+    eng.close()
