@@ -334,3 +334,21 @@ def test_limiter_quotes_its_own_fields():
         assert "counters not available" in bare and sorted(float(t) for t in re.findall(r"(?<![\w.])\d+\.\d+", bare)) == [0.07, 0.29]
     assert set(bench.BOUND) == {2, 3, 4, 5} and all(isinstance(v, str) for v in bench.BOUND.values())
     assert bench.backend_name("nccl").startswith("RCCL") and bench.backend_name("gloo").startswith("gloo")
+
+
+def test_tool_scripts_parse_and_are_listed():
+    """Every script under tools/ parses (bash -n / py_compile) and has a row in tools/README.md -- the GPU box is the wrong
+    place to find a syntax error, and an unlisted script is one nobody will find."""
+    import glob
+    import py_compile
+    import subprocess
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    readme = open(os.path.join(tools, "README.md")).read()
+    for f in sorted(glob.glob(os.path.join(tools, "*.sh"))):
+        r = subprocess.run(["bash", "-n", f], capture_output=True, text=True)
+        assert r.returncode == 0, (f, r.stderr)
+    for f in sorted(glob.glob(os.path.join(tools, "*.py"))):
+        py_compile.compile(f, doraise=True)
+    missing = [os.path.basename(f) for f in sorted(glob.glob(os.path.join(tools, "*.sh")) + glob.glob(os.path.join(tools, "*.py")) + glob.glob(os.path.join(tools, "*.hip")))
+               if os.path.basename(f) not in readme]
+    assert not missing, "not in tools/README.md: %s" % missing
