@@ -514,7 +514,8 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
   typedef typename std::conditional<FMT == FMT_C64, u32x2, unsigned short>::type raw_t;
   raw_t raw[16];
   const int start0 = p.starts[0];
-  auto issue_loads = [&](int fr, int k, int q0) {
+  auto issue_loads = [&](int fr, int k, int q0, auto rotc) {
+    constexpr int ROT = decltype(rotc)::value;   // ping-pong form: sample q lands in raw[(q + ROT) & 15]
     const char* fbase = reinterpret_cast<const char*>(p.iq) + (long long)fr * p.frame_stride * SB;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fbase), 0, p.frame_len * SB, 0x00020000);
     // reuse path: hops are constant (RM*L samples), so the start is arithmetic -- no dependent scalar load
@@ -524,14 +525,14 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
     for (int q = 0; q < 16; ++q) {
       if (q < q0) continue;
 #ifdef KSA_ABL_NOLOAD   // timing-only ablation build: wrong results by construction
-      if constexpr (FMT == FMT_C64) { raw[q].x = voff + q; raw[q].y = voff * q; }
-      else raw[q] = voff + q;
+      if constexpr (FMT == FMT_C64) { raw[(q + ROT) & 15].x = voff + q; raw[(q + ROT) & 15].y = voff * q; }
+      else raw[(q + ROT) & 15] = voff + q;
 #else
 #ifndef KSA_LOAD_AUX
 #define KSA_LOAD_AUX 0   // cache policy of the IQ loads (experiments: 2 = nt)
 #endif
-      if constexpr (FMT == FMT_C64) raw[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, L * q * SB, KSA_LOAD_AUX);
-      else raw[q] = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, L * q * SB, 0);
+      if constexpr (FMT == FMT_C64) raw[(q + ROT) & 15] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, L * q * SB, KSA_LOAD_AUX);
+      else raw[(q + ROT) & 15] = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, L * q * SB, 0);
 #endif
     }
   };
@@ -548,14 +549,26 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
 #ifndef KSA_PF
 #define KSA_PF 1   // reuse path: the RM new samples of window k+1 are requested while window k is transformed.  Fits since the
                    // transposed exchange layout of round 4: alone 155 VGPRs and no spill; together with the middle twiddles in
-                   // VGPRs (TWM_REGS) the N = 4096 reuse kernels sit at the 168-VGPR cap with TWO registers spilled (12 bytes of
-                   // scratch per lane), stored before the window loop and reloaded in the output stage -- never inside the loop
-                   // (tests/test_isa_regression.py holds the compiler to that).  +1.9 % at config 2, +0.6 % at 75 % overlap,
+                   // VGPRs (TWM_REGS) the N = 4096 reuse kernels sit at the 168-VGPR cap; what the rolled loop spills (2-8 registers:
+                   // 75 % overlap, MAX / MIN folds) is stored before the window loop and reloaded in the output stage -- never
+                   // inside the loop (tests/test_isa_regression.py holds the compiler to that).  +1.9 % at config 2, +0.6 % at 75 % overlap,
                    // +1..3 % at N = 2048; N = 1024 would spill 6-8 registers and large batches run the pair kernel there anyway
 #endif
   // (requesting the first window of the workgroup's NEXT frame before this frame's output stage, with LDS-only barriers
   //  around the staging stores so that the loads stay in flight, measured 2.5 % SLOWER at config 2: profiles/r04_ab_prefetch_twiddles.txt)
   constexpr bool PF = KSA_PF && RM > 0 && N >= 2048;
+  // Ping-pong form of the 50 %-overlap kernels of N = 4096 (round 5): at RM = 8 a window's new half is the next window's old half, so
+  // instead of moving registers every window (shift the carried half down, copy the prefetched half in: 24 v_mov_b64 per window in
+  // the rolled loop) the loop holds TWO windows and the halves of raw[] swap roles with the window's parity (ksa_window_body.inc is
+  // included twice, PAR = 0 / 1: sample q sits in raw[(q + 8*PAR) & 15], the prefetch lands in the half that has just been converted).
+  // 8 moves per window are left, the AVG kernel spills nothing any more (8 registers in the rolled form), and since every VALU
+  // instruction of this kernel costs its full issue time (profiles/r05_sensitivity_c2.txt) that is time: config 2 +1.8 %, uint8 input
+  // +3..5 % (profiles/r05_ab_pp.txt).  The body is an included file and not a lambda on purpose: as a generic lambda the same code made
+  // hipcc spill 9-12 registers in kernels that do not use it (N = 2048: 78 with it).
+#ifndef KSA_PP
+#define KSA_PP 1
+#endif
+  constexpr bool PP = KSA_PP && PF && RM == 8 && N == 4096;
   // (General path, RM == 0: letting the raw-sample registers take the NEXT round's 16 loads as soon as a round has converted
   //  them was measured at N = 64, round 5: 168 instead of 121 VGPRs = three instead of four waves per SIMD, config 4 14.9 vs
   //  17.7 G FFT/s (-16 %; uint8 -15 %); held to 128 VGPRs the same code spills 98-110 registers, with the 6-twiddle last pass
@@ -570,165 +583,24 @@ __global__ __launch_bounds__(Plan<N>::T, Tune<N>::WPS) void spectrum_kernel(cons
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = init;
 
-    for (int rd = 0; rd < rounds; ++rd) {
-      const int k = k_lo + (S == 1 ? rd : rd * S + slot);   // wave-uniform when one transform fills the workgroup
-      const bool active = S == 1 || k < k_hi;
-      float2 v[16];
-      float wpos[16];   // WIN_FUSED: the taps in the register order of v
-      if (PF) { if (rd == 0) issue_loads(frame, k, 0); }
-      else if (active) issue_loads(frame, k, (RM > 0 && rd > 0) ? 16 - RM : 0);
-      if (active) {
-        if constexpr (!WIN_LDS && Tune<N>::WIN_GLOBAL) {
-          // scalar descriptor + scalar offsets: no per-load address VGPRs
-          const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.window), 0, N * 4, 0x00020000);
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            win[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, l * 4, L * q * 4, 0)) * (FMT == FMT_U8 ? p.u8_inv_scale : 1.0f);
+    if constexpr (PP) {
+      for (int rd0 = 0; rd0 < rounds; rd0 += 2) {
+        {
+          const int rd = rd0;
+          constexpr int PAR = 0;
+#include "ksa_window_body.inc"
         }
-        if constexpr (WIN_LDS) {
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 w4 = reinterpret_cast<const float4*>(win_lds)[q4 * L + l];
-            win[4 * q4 + 0] = w4.x; win[4 * q4 + 1] = w4.y; win[4 * q4 + 2] = w4.z; win[4 * q4 + 3] = w4.w;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int pos = (q % B0) * R0 + (q / B0);
-          float2 x;
-          if constexpr (FMT == FMT_C64) {
-            // (scalar copies first: __builtin_bit_cast on a vector element reads element 0 twice)
-            const unsigned xr = raw[q].x, xi = raw[q].y;
-            x = make_float2(__uint_as_float(xr), __uint_as_float(xi));
-          } else {
-            const unsigned short b = raw[q];   // (b - offset)/scale * w, taps pre-divided by the scale
-            x = make_float2((float)(b & 0xff) - p.u8_offset, (float)(b >> 8) - p.u8_offset);
-          }
-          if constexpr (Tune<N>::WIN_FUSED) { v[pos] = x; wpos[pos] = win[q]; }
-          else v[pos] = make_float2(x.x * win[q], x.y * win[q]);
+        if (rd0 + 1 < rounds) {
+          const int rd = rd0 + 1;
+          constexpr int PAR = 1;
+#include "ksa_window_body.inc"
         }
       }
-      if (RM > 0) {
-        shift_raw();   // the next round of this frame loads only its RM new samples
-        // prefetch: the freed registers take window k+1's new samples now (unconditionally: after the frame's last
-        // window the same samples are simply requested again), in flight under the three passes
-        if (PF) issue_loads(frame, k + 1 < k_hi ? k + 1 : k, 16 - RM);
+    } else {
+      for (int rd = 0; rd < rounds; ++rd) {
+        constexpr int PAR = 0;
+#include "ksa_window_body.inc"
       }
-      KSA_STAMP(0);
-      if (active) {
-        if constexpr (Tune<N>::WIN_FUSED) dft_first_win<R0>(v, wpos);
-        else dft_first<R0>(v);
-      }
-      KSA_STAMP(1);
-      if constexpr (Tune<N>::QUAD_XCHG) {
-        // N = 64 = 4 * 16: butterfly i = l + 4b wrote output t to position 4l + 16b + t, the last pass reads
-        // l' + 4t': register 4b + j of lane l' must hold what register 4b + l' of lane j holds -- a 4x4 transpose
-        // inside the quad for every b, real and imaginary parts alike.  (The lanes of a quad share one slot, so
-        // `active` is uniform over the quad.)
-        static_assert(!Tune<N>::QUAD_XCHG || (L == 4 && R0 == 4 && M == 2), "quad exchange: N = 64 only");
-        const bool odd1 = l & 1, odd2 = l & 2;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          quad_transpose4(v[4 * b].x, v[4 * b + 1].x, v[4 * b + 2].x, v[4 * b + 3].x, odd1, odd2);
-          quad_transpose4(v[4 * b].y, v[4 * b + 1].y, v[4 * b + 2].y, v[4 * b + 3].y, odd1, odd2);
-        }
-        if (active) {
-          if constexpr (FUSED_LAST) dft16_fused(v, reinterpret_cast<const float2(&)[15]>(twl));
-          else dft16_tw(v, twl[0], twl[1], twl[2], twl[3], twl[4], twl[5]);
-        }
-      } else if constexpr (M >= 2) {
-        KSA_SYNC();  // previous round's / frame's LDS reads are done
-        KSA_STAMP(2);
-        if (active) {
-#pragma unroll
-          for (int b = 0; b < B0; ++b) {
-            const int i = l + b * L;  // butterfly index, p = 1
-#pragma unroll
-            for (int t = 0; t < R0; ++t) {
-              if constexpr (P::XLAYOUT) KSA_LDS_ST(my[perm<R0>(t) * P::ST1 + i], v[b * R0 + t]);   // transposed: [output][butterfly]
-              else KSA_LDS_ST(my[padi(i * R0 + perm<R0>(t))], v[b * R0 + t]);
-            }
-          }
-        }
-        KSA_SYNC();
-        KSA_STAMP(3);
-        int pp = R0;       // product of the radices already applied
-        int tw_off = 0;
-#pragma unroll
-        for (int s = 1; s < M; ++s) {
-          if (active) {
-            if constexpr (!P::XLAYOUT) {
-#pragma unroll
-              for (int t = 0; t < 16; ++t) KSA_LDS_LD(v[t], my[padi(l + L * t)]);
-            } else if (s == 1) {
-              // exchange 1, element l + L*t = output l % R0 of first-pass butterfly l / R0 + (L/R0)*t
-              const float2* const src = my + (l % R0) * P::ST1 + l / R0;
-#pragma unroll
-              for (int t = 0; t < 16; ++t) KSA_LDS_LD(v[t], src[(L / R0) * t]);
-            } else {
-              // exchange 2, element l + L*t in natural order with K2 pads per 2^SH2 (L = 2^SH2)
-              const float2* const src = my + l + P::K2 * (l >> P::SH2);
-#pragma unroll
-              for (int t = 0; t < 16; ++t) KSA_LDS_LD(v[t], src[(L + P::K2) * t]);
-            }
-            if (s < M - 1) {
-              const float2* tw = tw_lds + tw_off + (l & (pp - 1));
-              if constexpr (TWM_REGS) {
-                dft16_fused(v, reinterpret_cast<const float2(&)[15]>(twm));
-              } else if constexpr (FUSED) {
-                float2 tm[15];
-#pragma unroll
-                for (int e = 0; e < 15; ++e) tm[e] = tw[e * pp];
-                dft16_fused(v, tm);
-              } else {
-                dft16_tw(v, tw[0], tw[pp], tw[2 * pp], tw[3 * pp], tw[7 * pp], tw[11 * pp]);
-              }
-            } else {
-              if constexpr (FUSED_LAST) dft16_fused(v, reinterpret_cast<const float2(&)[15]>(twl));
-              else dft16_tw(v, twl[0], twl[1], twl[2], twl[3], twl[4], twl[5]);
-            }
-          }
-          KSA_STAMP(s < M - 1 ? 4 : 6);
-          if (s < M - 1) {
-            KSA_SYNC();
-            if (active) {
-              const int kk = l & (pp - 1);
-              const int j = (l - kk) * 16 + kk;
-              if constexpr (P::XLAYOUT) {       // (M == 3: pp == R0; every element of this butterfly shares j >> SH2 = l / pp)
-                float2* const dst = my + j + P::K2 * (l >> ilog2(R0));
-#pragma unroll
-                for (int t = 0; t < 16; ++t) KSA_LDS_ST(dst[perm<16>(t) * R0], v[t]);
-              } else {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) KSA_LDS_ST(my[padi(j + perm<16>(t) * pp)], v[t]);
-              }
-            }
-            KSA_SYNC();
-            KSA_STAMP(5);
-            tw_off += 15 * pp;
-            pp *= 16;
-          }
-        }
-      }
-      // ---- |X| and the fold over this block's windows (K:391-395) ----------------------------
-      if (active) {
-        const int cm = CM == 0 ? p.cumu : CM;   // CM != 0: the fold mode is a compile-time constant
-        if (cm == CUMU_AVG) {
-          // closed form of the (a+x)/2 recursion: weight 2^-(n-k+1), first window 2^-n
-          const int e = k == 0 ? nm1 : nm1 - k + 1;
-          const float w = ldexpf(1.0f, -e);
-#pragma unroll
-          for (int i = 0; i < 16; ++i)
-            acc[i] = fmaf(w, __builtin_amdgcn_sqrtf(fmaf(v[i].x, v[i].x, v[i].y * v[i].y)), acc[i]);
-        } else if (cm == CUMU_MAX) {      // np.max / np.min of K:141-143: a NaN window keeps the bin NaN
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = nan_max_nonneg(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = nan_min(acc[i], fmaf(v[i].x, v[i].x, v[i].y * v[i].y));
-        }
-      }
-      KSA_STAMP(7);
     }
 
     // ---- combine the slots, scale, fftshift, dB, waterfall row ------------------------------
