@@ -152,6 +152,7 @@ struct ksa_engine {
   int pair_bpc = 0, pair_vgprs = 0, pair_lds = 0;
   // N = 64, complex64: the 8 x 8 plan with adjacent-sample loads (ksa_kernels64.hpp)
   bool k64_ok = false;
+  bool win_ones = false;          // every tap of the window table is exactly 1.0f (the reference's default window, K:52)
   int k64_bpc = 0, k64_vgprs = 0;
   // profiling
   bool prof = false;
@@ -341,9 +342,9 @@ int launch_spec32(ksa_engine* e, const SpecParams& p, bool cfg_only) {
 }
 
 // N = 64, complex64 input: 8 x 8 with adjacent samples per lane (ksa_kernels64.hpp)
-template <int CM>
+template <int CM, bool W1>
 int launch_spec64_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
-  auto kfn = ksa::spectrum64_kernel<ksa::FMT_C64, CM>;
+  auto kfn = ksa::spectrum64_kernel<ksa::FMT_C64, CM, W1>;
   if (configure_only) {
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, ksa::Plan64::LDS_BYTES));
     int occ = 0;
@@ -362,14 +363,19 @@ int launch_spec64_c(ksa_engine* e, const SpecParams& p, bool configure_only) {
   return 0;
 }
 
-int launch_spec64(ksa_engine* e, const SpecParams& p, bool cfg_only) {
+template <bool W1>
+int launch_spec64_w(ksa_engine* e, const SpecParams& p, bool cfg_only) {
   if (cfg_only) {
-    if (launch_spec64_c<ksa::CUMU_MAX>(e, p, true) || launch_spec64_c<ksa::CUMU_MIN>(e, p, true)) return 1;
-    return launch_spec64_c<ksa::CUMU_AVG>(e, p, true);
+    if (launch_spec64_c<ksa::CUMU_MAX, W1>(e, p, true) || launch_spec64_c<ksa::CUMU_MIN, W1>(e, p, true)) return 1;
+    return launch_spec64_c<ksa::CUMU_AVG, W1>(e, p, true);
   }
-  if (p.cumu == ksa::CUMU_AVG) return launch_spec64_c<ksa::CUMU_AVG>(e, p, false);
-  if (p.cumu == ksa::CUMU_MAX) return launch_spec64_c<ksa::CUMU_MAX>(e, p, false);
-  return launch_spec64_c<ksa::CUMU_MIN>(e, p, false);
+  if (p.cumu == ksa::CUMU_AVG) return launch_spec64_c<ksa::CUMU_AVG, W1>(e, p, false);
+  if (p.cumu == ksa::CUMU_MAX) return launch_spec64_c<ksa::CUMU_MAX, W1>(e, p, false);
+  return launch_spec64_c<ksa::CUMU_MIN, W1>(e, p, false);
+}
+int launch_spec64(ksa_engine* e, const SpecParams& p, bool cfg_only) {
+  // (p.window is the engine's own table here: the first-stage paths, which hand this stage a table of ones, start at N = 32768)
+  return e->win_ones && !exp_env("KSA_NO_W1") ? launch_spec64_w<true>(e, p, cfg_only) : launch_spec64_w<false>(e, p, cfg_only);
 }
 
 template <int FMT>
@@ -708,6 +714,7 @@ int ksa_create(const ksa_config* cfg, ksa_engine** out) {
   if ((rc = upload(&e->d_starts, cfg->window_starts, (size_t)cfg->num_windows))) return bail(rc);
   if ((rc = upload(&e->d_start_last, cfg->window_starts + cfg->num_windows - 1, 1))) return bail(rc);
   if ((rc = upload(&e->d_window, cfg->window, (size_t)n))) return bail(rc);
+  e->win_ones = std::all_of(cfg->window, cfg->window + n, [](float w) { return w == 1.0f; });
 
   {
     e->path = n <= 16384 ? 0 : 2;

@@ -262,6 +262,24 @@ def test_n64_complex_input_runs_the_8x8_kernel_within_its_register_budget(ksa):
     eng.close()
 
 
+def test_n64_rectangular_window_kernel_equals_the_generic_one(ksa):
+    """An all-ones window table selects spectrum64_kernel<.., W1 = true> (no tap multiplies; the reference's default window,
+    K:52).  A table that is all ones except ONE tap of 1 + 2^-23 runs the generic kernel: the two spectra must agree to the
+    last-bit effect of that one tap (and each with the oracle) -- x * 1.0f is x."""
+    n, full, q = 64, 512, 0.1
+    x = orc.synth_iq(full, 909).astype(np.complex64)
+    ones = np.ones(n, dtype=np.float32)
+    almost = ones.copy()
+    almost[17] = np.nextafter(np.float32(1.0), np.float32(2.0))
+    for m in ("AVG", "MAX", "MIN"):
+        a = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window="ones", cumu_mode=m)
+        b = ksa.SpectrumEngine(n, full_size=full, non_overlap=q, window=almost, cumu_mode=m)
+        ya, yb = a.curscan(x), b.curscan(x)
+        assert_lin(ya, orc.curscan(x, n, q, ones.astype(np.float64), m), what="W1 " + m)
+        assert np.max(np.abs(ya - yb)) <= 4e-7 * np.max(ya), "the rectangular-window kernel differs from the generic one by more than one tap's last bit"
+        a.close(); b.close()
+
+
 @pytest.mark.parametrize("full,q", [(64, 0.5), (100, 0.1), (160, 0.5), (512, 0.1), (512, 0.25), (1100, 0.5), (1111, 0.07), (4096, 0.1)])
 def test_n64_8x8_kernel_every_fold_mode_and_round_shape(ksa, torch_cuda, full, q):
     """spectrum64_kernel against the oracle's curscan (K:351-397) for window counts of 1, one partial round, exact multiples of

@@ -8,7 +8,7 @@ config-2 kernel has none at all).  Nothing in the
 numeric suites would notice a toolchain or source change that breaks either: the results stay right, only slower.
 
 This test compiles the product translation unit (csrc/ksa_api.hip, the flags of build.py) to device assembly and checks, for
-the three kernels the bench configurations run -- spectrum_kernel<4096,c64,RM=8,AVG> (config 2), spectrum64_kernel<c64,AVG>
+the three kernels the bench configurations run -- spectrum_kernel<4096,c64,RM=8,AVG> (config 2), spectrum64_kernel<c64,AVG,ones>
 (config 4), spectrum32_kernel<16384,c64,AVG> (config 3) --: VGPRs / occupancy / scratch bytes as DESIGN.md states them, the
 instruction mix of the window loop (the innermost loop that holds the fold's 16 / 32 v_sqrt_f32), no merged exchange reads, no
 scratch traffic where the design says there is none.  A second, small translation unit with -DKSA_LDS_ATOMIC_LD=0 proves that
@@ -114,11 +114,16 @@ def test_config4_kernel_runs_four_waves_per_simd_without_scratch(product_asm):
     """spectrum64_kernel<c64, AVG> (the 8 x 8 plan of round 5): single-wave workgroups, <= 128 VGPRs (four waves per SIMD), no
     scratch, EIGHT 16-byte sample loads per round (two adjacent samples each -- the point of the plan), the one exchange read
     back by 16 single ds_read_b64; and spectrum_kernel<64, ., 0, AVG>, which uint8 input still runs, as before."""
-    body, tail = _find(product_asm, "spectrum64_kernel<0, 1>")
-    assert _resource(tail, "NumVgprs") <= 128 and _resource(tail, "Occupancy") >= 4 and _resource(tail, "ScratchSize") == 0
-    loop = _mix(_window_loop(body, 16))
-    assert loop["buffer_load_dwordx4"] == 8 and loop["buffer_load_dwordx2"] == 0, dict(loop)
-    assert loop["ds_read_b64"] >= 16 and loop["ds_read2_b64"] + loop["ds_read2st64_b64"] == 0, dict(loop)
+    mixes = {}
+    for w1 in ("false", "true"):       # true: the all-ones window table (the reference's default, what config 4 runs): no tap reads, no multiplies
+        body, tail = _find(product_asm, "spectrum64_kernel<0, 1, %s>" % w1)
+        assert _resource(tail, "NumVgprs") <= 128 and _resource(tail, "Occupancy") >= 4 and _resource(tail, "ScratchSize") == 0
+        loop = mixes[w1] = _mix(_window_loop(body, 16))
+        assert loop["buffer_load_dwordx4"] == 8 and loop["buffer_load_dwordx2"] == 0, dict(loop)
+        assert loop["ds_read_b64"] >= 16 and loop["ds_read2_b64"] + loop["ds_read2st64_b64"] == 0, dict(loop)
+    assert mixes["true"]["ds_read_b128"] == 0 and mixes["false"]["ds_read_b128"] + mixes["false"]["ds_read_b64"] > mixes["true"]["ds_read_b64"]
+    valu = lambda m: sum(v for k, v in m.items() if k.startswith("v_"))
+    assert valu(mixes["true"]) <= valu(mixes["false"]) - 16, "the rectangular-window kernel still multiplies by its taps"
     for name in ("spectrum_kernel<64, 0, 0, 1>", "spectrum_kernel<64, 1, 0, 1>"):
         body, tail = _find(product_asm, name)
         assert _resource(tail, "NumVgprs") <= 128 and _resource(tail, "Occupancy") >= 4 and _resource(tail, "ScratchSize") == 0
